@@ -1,0 +1,123 @@
+"""Deterministic synthetic inputs for the SED hot path: clips and CRNN weights.
+
+Nothing here touches a GPU or the oracle.  Both the parity tests and the
+benchmark draw their inputs from these generators so that the CPU checker and
+the HIP path always see identical bytes, and so that no weight file has to be
+committed (the reference's own ``weights_{fold}.pth`` files are not
+distributed with it: /root/reference/.gitignore:3).
+
+Clip i is white noise of amplitude 0.1 from ``PCG64(1234 + i)`` plus one to
+four gated sinusoid bursts, which gives the classifier something to fire on.
+Weights follow the state_dict schema of the reference's baseline CRNN as it is
+constructed at training.py:207-212 (83 keys, see ``crnn_state_dict_spec``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+# training.py:207-212 — the only CRNN configuration the reference ever builds.
+CRNN_FILTERS = (16, 32, 64, 128, 128, 128, 128)
+CRNN_POOLING = ((2, 2), (1, 2), (1, 2), (1, 2), (1, 2), (1, 2), (1, 2))
+CRNN_HIDDEN = 128
+CRNN_GRU_LAYERS = 2
+
+
+def synth_clip(index: int, n_samples: int = 160000, sr: int = 16000) -> np.ndarray:
+    """Clip ``index``: float32 [n_samples], noise 0.1 rms + 1..4 tone bursts."""
+    rng = np.random.Generator(np.random.PCG64(1234 + int(index)))
+    y = rng.standard_normal(n_samples).astype(np.float32) * np.float32(0.1)
+    n_bursts = int(rng.integers(1, 5))
+    t = np.arange(n_samples, dtype=np.float64) / float(sr)
+    for _ in range(n_bursts):
+        f0 = float(rng.uniform(200.0, 0.45 * sr))
+        amp = float(rng.uniform(0.1, 0.5))
+        start = int(rng.integers(0, max(1, n_samples - sr // 4)))
+        length = int(rng.integers(sr // 4, 3 * sr))
+        stop = min(n_samples, start + length)
+        y[start:stop] += (amp * np.sin(2.0 * np.pi * f0 * t[start:stop])).astype(np.float32)
+    return y
+
+
+def synth_clips(first: int, count: int, n_samples: int = 160000, sr: int = 16000) -> np.ndarray:
+    """float32 [count, n_samples], clip indices first .. first+count-1."""
+    out = np.empty((count, n_samples), dtype=np.float32)
+    for k in range(count):
+        out[k] = synth_clip(first + k, n_samples, sr)
+    return out
+
+
+def crnn_state_dict_spec(nclass: int = 10, n_in_channel: int = 1,
+                         filters=CRNN_FILTERS, hidden: int = CRNN_HIDDEN,
+                         gru_layers: int = CRNN_GRU_LAYERS):
+    """Ordered (key, shape) list of the baseline CRNN's state_dict.
+
+    Key names are those PyTorch derives from the reference's module tree:
+    nnet/CNN.py:69-91 (conv{i}, batchnorm{i}, glu{i}.linear inside the
+    ``cnn`` Sequential of ``CNN``, itself the ``cnn`` attribute of ``CRNN``),
+    nnet/RNN.py:19-26 (``rnn.rnn`` = nn.GRU), nnet/CRNN.py:109-113 (dense,
+    dense_softmax).
+    """
+    spec = []
+    cin = n_in_channel
+    for i, cout in enumerate(filters):
+        p = f"cnn.cnn.conv{i}"
+        spec += [(f"{p}.weight", (cout, cin, 3, 3)), (f"{p}.bias", (cout,))]
+        p = f"cnn.cnn.batchnorm{i}"
+        spec += [(f"{p}.weight", (cout,)), (f"{p}.bias", (cout,)),
+                 (f"{p}.running_mean", (cout,)), (f"{p}.running_var", (cout,)),
+                 (f"{p}.num_batches_tracked", ())]
+        p = f"cnn.cnn.glu{i}.linear"
+        spec += [(f"{p}.weight", (cout, cout)), (f"{p}.bias", (cout,))]
+        cin = cout
+    for layer in range(gru_layers):
+        n_in = filters[-1] if layer == 0 else 2 * hidden
+        for sfx in ("", "_reverse"):
+            spec += [(f"rnn.rnn.weight_ih_l{layer}{sfx}", (3 * hidden, n_in)),
+                     (f"rnn.rnn.weight_hh_l{layer}{sfx}", (3 * hidden, hidden)),
+                     (f"rnn.rnn.bias_ih_l{layer}{sfx}", (3 * hidden,)),
+                     (f"rnn.rnn.bias_hh_l{layer}{sfx}", (3 * hidden,))]
+    spec += [("dense.weight", (nclass, 2 * hidden)), ("dense.bias", (nclass,)),
+             ("dense_softmax.weight", (nclass, 2 * hidden)), ("dense_softmax.bias", (nclass,))]
+    return spec
+
+
+def synth_crnn_state_dict(seed: int = 0, nclass: int = 10, head_gain: float = 6.0):
+    """Deterministic CRNN weights as an ordered dict of CPU float32 tensors.
+
+    Fan-in scaled uniform weights; BatchNorm statistics near (0, 1) except the
+    first layer, whose running_var is sized to the power-mel input range; the
+    strong head is scaled by ``head_gain`` so that frame probabilities spread
+    on both sides of 0.5 instead of sitting at 0.5 +- 0.02.
+    """
+    rng = np.random.Generator(np.random.PCG64(977 + int(seed)))
+    sd = {}
+    for key, shape in crnn_state_dict_spec(nclass):
+        leaf = key.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[key] = torch.tensor(100, dtype=torch.int64)
+            continue
+        if "batchnorm" in key:
+            first = key.startswith("cnn.cnn.batchnorm0.")
+            if leaf == "weight":
+                v = rng.uniform(0.8, 1.2, shape)
+            elif leaf == "bias":
+                v = rng.uniform(-0.1, 0.1, shape)
+            elif leaf == "running_mean":
+                v = rng.uniform(-0.1, 0.1, shape) + (0.2 if first else 0.0)
+            else:  # running_var
+                v = rng.uniform(0.8, 1.2, shape) * (9.0 if first else 1.0)
+        elif leaf.startswith("bias"):
+            v = rng.uniform(-0.1, 0.1, shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            bound = np.sqrt(3.0 / fan_in)
+            if key.startswith("cnn.cnn.conv"):
+                bound *= 1.25         # keeps the signal alive through 7 GLU gates
+            if ".glu" in key:
+                bound *= 1.45
+            if key == "dense.weight":
+                bound *= head_gain
+            v = rng.uniform(-bound, bound, shape)
+        sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
+    return sd
