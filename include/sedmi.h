@@ -1,0 +1,205 @@
+/*
+ * sedmi.h — C ABI of libsedmi.so: the MI355X (gfx950) implementation of the
+ * sound-event-detection inference hot path
+ *
+ *     mel frontend  ->  baseline CRNN (conv blocks + bidirectional GRU + head)
+ *                   ->  threshold / run-length event decode
+ *
+ * The reference (Willi-bot/Sound-Event-Detection) is pure Python and has no
+ * FFI of its own; each entry point below states which reference call it
+ * stands in for (file:line under the reference's root).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SEDMI_E* code; the
+ *     text of the last error on the calling thread is sedmi_last_error();
+ *   - no C++ exceptions cross this boundary, no torch types appear in it;
+ *   - "device pointer" = memory of the current HIP device, owned by the
+ *     caller (typically a PyTorch-ROCm tensor's data_ptr()); "host pointer" =
+ *     ordinary CPU memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     work is enqueued on it and the call returns without synchronising,
+ *     except where a function says it synchronises;
+ *   - handles own the device memory they allocate and free it in *_destroy;
+ *     a handle belongs to the device that was current when it was created.
+ */
+#ifndef SEDMI_H
+#define SEDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEDMI_OK            0
+#define SEDMI_EINVAL       -1   /* bad argument / unsupported shape          */
+#define SEDMI_EHIP         -2   /* a HIP runtime call failed                 */
+#define SEDMI_ENOMEM       -3   /* workspace or capacity too small           */
+#define SEDMI_ENODEV       -4   /* no usable gfx950 device                   */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int sedmi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *sedmi_last_error(void);
+/* Number of visible HIP devices, or a negative SEDMI_E* code. */
+int sedmi_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Mel frontend.
+ * Replaces librosa.feature.melspectrogram(y=, sr=, n_fft=, n_mels=,
+ * hop_length=, win_length=) as called at feature_extraction.py:45-46
+ * (periodic Hann window centred in n_fft, centre padding with zeros,
+ * power 2.0, Slaney mel scale and area normalisation, fmin 0, fmax sr/2).
+ * ------------------------------------------------------------------------ */
+typedef struct sedmi_mel_plan sedmi_mel_plan;
+
+/* flags for sedmi_melspec_f32 — both OFF reproduces the reference, which has
+ * neither stage */
+#define SEDMI_MEL_LOG        1  /* 10*log10(max(S, 1e-10)) after the projection */
+#define SEDMI_MEL_NORMALISE  2  /* (x - mean[m]) * istd[m] per mel bin, after log */
+
+/* Builds window, twiddle and sparse filterbank tables on the current device.
+ * n_fft must be 1024, 2048 or 4096; 0 < win_length <= n_fft; hop_length > 0;
+ * 0 < n_mels <= 1024. */
+int sedmi_mel_plan_create(sedmi_mel_plan **plan, int sr, int n_fft, int win_length,
+                          int hop_length, int n_mels);
+int sedmi_mel_plan_destroy(sedmi_mel_plan *plan);
+/* Frames per clip of n_samples samples: 1 + n_samples / hop_length. */
+int64_t sedmi_mel_num_frames(const sedmi_mel_plan *plan, int64_t n_samples);
+/* Copies the dense float32 filterbank [n_mels, 1 + n_fft/2] to a host buffer
+ * (for inspection and tests). */
+int sedmi_mel_filterbank(const sedmi_mel_plan *plan, float *host_out);
+
+/* y: device float32 [n_clips, n_samples] (contiguous).
+ * out: device float32 [n_clips, n_mels, T], T = sedmi_mel_num_frames(): the
+ * mel-major array librosa returns.  The reference then re-reads the same
+ * bytes as [T, n_mels] (np.reshape at feature_extraction.py:49-50), which
+ * needs no data movement: pass `out` on as the [n_clips, T, n_mels] feature.
+ * mean / istd: device float32 [n_mels], read only with SEDMI_MEL_NORMALISE. */
+int sedmi_melspec_f32(const sedmi_mel_plan *plan, const float *y, int64_t n_clips,
+                      int64_t n_samples, int flags, const float *mean, const float *istd,
+                      float *out, void *stream);
+
+/* Per-mel-bin sum and sum of squares over all clips and frames of a
+ * [n_clips, n_mels, T] array, accumulated in float64 into device buffers
+ * sum[n_mels], sumsq[n_mels] (ADDED to their current contents, so that ranks
+ * can all-reduce them).  Supports the optional normalisation stage; the
+ * reference has no counterpart (its --normalize flag is never read:
+ * training.py:91-94). */
+int sedmi_mel_stats_f64(const float *mel, int64_t n_clips, int n_mels, int64_t T,
+                        double *sum, double *sumsq, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Baseline CRNN, eval-mode forward.
+ * Replaces CRNN.forward (nnet/CRNN.py:191-268) for the one configuration the
+ * reference constructs (training.py:207-212): 7 x [Conv3x3 -> BatchNorm(eps
+ * 1e-3) -> GLU -> AvgPool] (nnet/CNN.py:66-98), 2-layer bidirectional GRU
+ * (nnet/RNN.py:19-30), strong head sigmoid(Linear) (nnet/CRNN.py:142-143).
+ * ------------------------------------------------------------------------ */
+typedef struct sedmi_crnn sedmi_crnn;
+
+#define SEDMI_CRNN_LAYERS 7
+
+/* Host pointers to float32 tensors in the reference's state_dict layout. */
+typedef struct sedmi_crnn_weights {
+    int n_class;                                   /* rows of dense.weight            */
+    int n_freq;                                    /* input feature width (128)        */
+    int filters[SEDMI_CRNN_LAYERS];                /* 16,32,64,128,128,128,128         */
+    int pool_t[SEDMI_CRNN_LAYERS];                 /* time pooling per block (2,1,...) */
+    int pool_f[SEDMI_CRNN_LAYERS];                 /* freq pooling per block (2,2,...) */
+    int hidden;                                    /* GRU hidden size (128)            */
+    float bn_eps;                                  /* 1e-3                             */
+    const float *conv_w[SEDMI_CRNN_LAYERS];        /* cnn.cnn.conv{i}.weight [Co,Ci,3,3] */
+    const float *conv_b[SEDMI_CRNN_LAYERS];        /* cnn.cnn.conv{i}.bias   [Co]        */
+    const float *bn_w[SEDMI_CRNN_LAYERS];          /* cnn.cnn.batchnorm{i}.weight        */
+    const float *bn_b[SEDMI_CRNN_LAYERS];          /* ....bias                           */
+    const float *bn_mean[SEDMI_CRNN_LAYERS];       /* ....running_mean                   */
+    const float *bn_var[SEDMI_CRNN_LAYERS];        /* ....running_var                    */
+    const float *glu_w[SEDMI_CRNN_LAYERS];         /* cnn.cnn.glu{i}.linear.weight [Co,Co] */
+    const float *glu_b[SEDMI_CRNN_LAYERS];         /* ....bias [Co]                      */
+    /* rnn.rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{L}[_reverse]; index [L][dir] */
+    const float *gru_w_ih[2][2];
+    const float *gru_w_hh[2][2];
+    const float *gru_b_ih[2][2];
+    const float *gru_b_hh[2][2];
+    const float *dense_w;                          /* dense.weight [n_class, 2*hidden]   */
+    const float *dense_b;                          /* dense.bias   [n_class]             */
+} sedmi_crnn_weights;
+
+/* Folds BatchNorm into the convolutions, repacks every matrix into the
+ * layout its kernel reads, and uploads the result to the current device. */
+int sedmi_crnn_create(sedmi_crnn **model, const sedmi_crnn_weights *w);
+int sedmi_crnn_destroy(sedmi_crnn *model);
+/* Output frames for T input frames (product of the time poolings, floored). */
+int64_t sedmi_crnn_out_frames(const sedmi_crnn *model, int64_t T);
+/* Scratch bytes sedmi_crnn_forward_f32 needs for a batch of n_clips x T. */
+size_t sedmi_crnn_workspace_bytes(const sedmi_crnn *model, int64_t n_clips, int64_t T);
+
+/* feats: device float32 [n_clips, T, n_freq]; probs: device float32
+ * [n_clips, T', n_class] (probabilities, as CRNN.forward returns them);
+ * ws: device scratch of at least sedmi_crnn_workspace_bytes(). */
+int sedmi_crnn_forward_f32(const sedmi_crnn *model, const float *feats, int64_t n_clips,
+                           int64_t T, float *probs, void *ws, size_t ws_bytes, void *stream);
+
+/* Stage-level entry points (same arithmetic as inside the full forward; used
+ * by the layer-level parity tests).
+ * sedmi_crnn_cnn_f32:  feats [n, T, n_freq] -> seq [n, T', C_last]
+ *   (= CNN.forward + squeeze(-1).permute(0,2,1), nnet/CRNN.py:200,212-213).
+ * sedmi_crnn_gru_f32:  seq [n, T', C_last] -> rec [n, T', 2*hidden]
+ *   (= BidirectionalGRU.forward, nnet/RNN.py:28-30).
+ * sedmi_crnn_head_f32: rec [n*T', 2*hidden] -> probs [n*T', n_class]. */
+int sedmi_crnn_cnn_f32(const sedmi_crnn *model, const float *feats, int64_t n_clips, int64_t T,
+                       float *seq, void *ws, size_t ws_bytes, void *stream);
+int sedmi_crnn_gru_f32(const sedmi_crnn *model, const float *seq, int64_t n_clips, int64_t Tp,
+                       float *rec, void *ws, size_t ws_bytes, void *stream);
+int sedmi_crnn_head_f32(const sedmi_crnn *model, const float *rec, int64_t n_rows,
+                        float *probs, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Thresholding and event decoding.
+ * ------------------------------------------------------------------------ */
+
+/* out[i] = (sigmoid?(p[i]) > thr) ? 1 : 0 as int64 — the thresholding half of
+ * evaluate() (evaluation.py:19-21): strict '>', int64 result. */
+int sedmi_threshold_i64(const float *p, int64_t n, float thr, int apply_sigmoid,
+                        int64_t *out, void *stream);
+
+/* Run-length event decode of get_prediction_from_raw_output
+ * (evaluation.py:49-80) for many recordings at once.
+ *   p           device float32 [total_frames, n_class], recordings back to back
+ *   seg_start   device int64 [n_seg + 1]: recording s owns frames
+ *               [seg_start[s], seg_start[s+1])
+ *   seg_cutoff  device int64 [n_seg]: frames kept per recording
+ *               (int(duration / block) + 1, evaluation.py:58); values larger
+ *               than the recording are clamped to it
+ *   median_win  odd window of the optional median filter over time (1 = off,
+ *               which is the reference's behaviour; reflect boundary)
+ * Output, ordered by recording, then class, then onset (evaluation.py:61):
+ *   ev_seg/ev_cls/ev_on/ev_off  device int32 [capacity]; offsets are
+ *               exclusive frame indices relative to the recording
+ *   n_events    device int64 [1]: number of events found (may exceed
+ *               capacity, in which case only the first `capacity` are stored)
+ *   ws          device scratch >= sedmi_decode_workspace_bytes(n_seg, n_class)
+ * Event times in seconds are frame_index * (block_ms / 1000.0) in float64,
+ * computed by the caller exactly as evaluation.py:55,75-76 does. */
+size_t sedmi_decode_workspace_bytes(int64_t n_seg, int n_class);
+int sedmi_decode_events(const float *p, int64_t total_frames, int n_class,
+                        const int64_t *seg_start, const int64_t *seg_cutoff, int64_t n_seg,
+                        float thr, int apply_sigmoid, int median_win,
+                        int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off,
+                        int64_t capacity, int64_t *n_events, void *ws, size_t ws_bytes,
+                        void *stream);
+
+/* Per-class confusion counts of thresholded predictions against 0/1 labels —
+ * the sufficient statistics of the sklearn scores in evaluate()
+ * (evaluation.py:26-45).  labels: device float32 [n_rows, n_class] (the
+ * dtype data_loading.py:39 produces); counts: device int64 [n_class, 4] =
+ * TP, FP, FN, TN, ADDED to current contents. */
+int sedmi_confusion_counts(const float *p, const float *labels, int64_t n_rows, int n_class,
+                           float thr, int apply_sigmoid, int64_t *counts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEDMI_H */

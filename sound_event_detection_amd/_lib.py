@@ -1,0 +1,100 @@
+"""ctypes binding of libsedmi.so (the C ABI declared in include/sedmi.h).
+
+There is no CPU fallback: if the shared library is missing or an entry point
+fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsedmi.so")
+
+SEDMI_MEL_LOG = 1
+SEDMI_MEL_NORMALISE = 2
+CRNN_LAYERS = 7
+
+
+class SedmiError(RuntimeError):
+    pass
+
+
+class CrnnWeights(C.Structure):
+    _FP = C.POINTER(C.c_float)
+    _fields_ = [
+        ("n_class", C.c_int), ("n_freq", C.c_int),
+        ("filters", C.c_int * CRNN_LAYERS), ("pool_t", C.c_int * CRNN_LAYERS),
+        ("pool_f", C.c_int * CRNN_LAYERS), ("hidden", C.c_int), ("bn_eps", C.c_float),
+        ("conv_w", _FP * CRNN_LAYERS), ("conv_b", _FP * CRNN_LAYERS),
+        ("bn_w", _FP * CRNN_LAYERS), ("bn_b", _FP * CRNN_LAYERS),
+        ("bn_mean", _FP * CRNN_LAYERS), ("bn_var", _FP * CRNN_LAYERS),
+        ("glu_w", _FP * CRNN_LAYERS), ("glu_b", _FP * CRNN_LAYERS),
+        ("gru_w_ih", (_FP * 2) * 2), ("gru_w_hh", (_FP * 2) * 2),
+        ("gru_b_ih", (_FP * 2) * 2), ("gru_b_hh", (_FP * 2) * 2),
+        ("dense_w", _FP), ("dense_b", _FP),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/sedmi.h declares
+_VP, _I64, _SZ, _F, _I = C.c_void_p, C.c_int64, C.c_size_t, C.c_float, C.c_int
+SIGNATURES = {
+    "sedmi_version": (_I, []),
+    "sedmi_last_error": (C.c_char_p, []),
+    "sedmi_device_count": (_I, []),
+    "sedmi_mel_plan_create": (_I, [C.POINTER(_VP), _I, _I, _I, _I, _I]),
+    "sedmi_mel_plan_destroy": (_I, [_VP]),
+    "sedmi_mel_num_frames": (_I64, [_VP, _I64]),
+    "sedmi_mel_filterbank": (_I, [_VP, _VP]),
+    "sedmi_melspec_f32": (_I, [_VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
+    "sedmi_mel_stats_f64": (_I, [_VP, _I64, _I, _I64, _VP, _VP, _VP]),
+    "sedmi_crnn_create": (_I, [C.POINTER(_VP), C.POINTER(CrnnWeights)]),
+    "sedmi_crnn_destroy": (_I, [_VP]),
+    "sedmi_crnn_out_frames": (_I64, [_VP, _I64]),
+    "sedmi_crnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
+    "sedmi_crnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
+    "sedmi_crnn_cnn_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
+    "sedmi_crnn_gru_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
+    "sedmi_crnn_head_f32": (_I, [_VP, _VP, _I64, _VP, _VP]),
+    "sedmi_threshold_i64": (_I, [_VP, _I64, _F, _I, _VP, _VP]),
+    "sedmi_decode_workspace_bytes": (_SZ, [_I64, _I]),
+    "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,
+                                 _I64, _VP, _VP, _SZ, _VP]),
+    "sedmi_confusion_counts": (_I, [_VP, _VP, _I64, _I, _F, _I, _VP, _VP]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SedmiError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C sound_event_detection_amd/csrc`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = lib().sedmi_last_error().decode("utf-8", "replace")
+        raise SedmiError(f"{what or 'sedmi call'} failed ({rc}): {msg}")
+    return rc
+
+
+def ptr(t) -> C.c_void_p:
+    """Device (or host) address of a torch tensor / None."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr(device) -> C.c_void_p:
+    """The hipStream_t torch is currently enqueueing on for ``device``."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

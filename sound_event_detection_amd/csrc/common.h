@@ -1,0 +1,50 @@
+// Shared host-side helpers of libsedmi: error reporting and small utilities.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sedmi.h"
+
+namespace sedmi {
+
+// Thread-local message returned by sedmi_last_error().
+char *error_buffer();
+int set_error(int code, const char *fmt, ...);
+
+#define SEDMI_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return ::sedmi::set_error(SEDMI_EHIP, "%s failed: %s (%s:%d)", #expr,          \
+                                      hipGetErrorString(e_), __FILE__, __LINE__);          \
+    } while (0)
+
+#define SEDMI_REQUIRE(cond, ...)                                                           \
+    do {                                                                                   \
+        if (!(cond)) return ::sedmi::set_error(SEDMI_EINVAL, __VA_ARGS__);                 \
+    } while (0)
+
+// Launch-error check that does not synchronise.
+#define SEDMI_CHECK_LAUNCH() SEDMI_CHECK_HIP(hipGetLastError())
+
+template <typename T>
+int upload(T **dev, const std::vector<T> &host) {
+    *dev = nullptr;
+    size_t bytes = host.size() * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    SEDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(dev), bytes));
+    if (!host.empty())
+        SEDMI_CHECK_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SEDMI_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace sedmi

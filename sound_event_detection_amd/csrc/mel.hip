@@ -1,0 +1,549 @@
+// Mel frontend for gfx950: framing + Hann window + real FFT + power + sparse
+// Slaney mel projection (+ optional log / normalisation), fused in one kernel.
+//
+// Stands in for librosa.feature.melspectrogram as the reference calls it at
+// feature_extraction.py:45-46; the arithmetic follows librosa's published
+// algorithm (stft with center=True / pad_mode="constant" / periodic Hann padded
+// to n_fft, power 2.0, filters.mel with Slaney scale and normalisation).
+//
+// Kernel shape
+//   * one wave (64 lanes) transforms one frame: the n_fft real samples are
+//     packed into NC = n_fft/2 complex points and run through a
+//     R1 x 4 x 16 Cooley-Tukey split (R1 = NC/64) whose butterflies live in
+//     registers; the three stages exchange data through a per-wave LDS
+//     scratch (three transposes), then each lane untangles bin pairs
+//     (k, NC-k) of the real spectrum and writes |X|^2 into a block-shared
+//     power tile P[bin][frame];
+//   * a workgroup owns FPB consecutive frames of one clip; after a barrier
+//     it applies the filterbank as a sparse contraction (every filter is a
+//     short contiguous run of bins: 2020 non-zeros of 131200 for 128 mels at
+//     n_fft 2048), lanes = (filter, frame) so that all lanes of a wave run
+//     the same trip count and the weights are LDS broadcasts;
+//   * output is written mel-major [clip][mel][frame], FPB frames (64 B) at a
+//     time; the reference's "reshape" of that array is a free reinterpretation.
+//   * workgroups are persistent over (clip, tile) work items so that the
+//     per-lane twiddles and window taps are loaded once and stay in VGPRs.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+struct MelArgs {
+    const float *y;
+    long n_samples;
+    int T;
+    int hop;
+    int n_fft;
+    const float *win;        // [n_fft] window, zero outside the centred Hann
+    const float2 *tw_nc;     // [NC]      exp(-2 pi i j / NC)
+    const float2 *tw_post;   // [NC/2+1]  exp(-2 pi i k / (2 NC))
+    int zlo, zhi;            // complex indices with a non-zero window tap: [zlo, zhi)
+    int n_mels;
+    const int *mel_start;    // first bin of each filter
+    const int *mel_len;      // number of bins
+    const int *mel_ptr;      // offset into mel_w
+    const float *mel_w;
+    int nnz;
+    float *out;
+    int flags;
+    const float *mean;
+    const float *istd;
+    int tiles_per_clip;
+    long total_tiles;
+};
+
+// cos / sin of 2*pi*i/32 from exact literals (so that the unrolled butterflies
+// get compile-time twiddles).
+__host__ __device__ constexpr float cos32(int i) {
+    constexpr float C[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                            0.83146961230254523708f, 0.70710678118654752440f,
+                            0.55557023301960222474f, 0.38268343236508977173f,
+                            0.19509032201612826785f, 0.0f};
+    i &= 31;
+    if (i > 16) i = 32 - i;
+    return i > 8 ? -C[16 - i] : C[i];
+}
+__host__ __device__ constexpr float sin32(int i) { return cos32(i - 8); }
+
+template <int R>
+__host__ __device__ constexpr int bitrev(int x) {
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+// In-register radix-2 decimation-in-frequency DFT of R points, forward sign.
+// On return element p holds X[bitrev<R>(p)].
+template <int R>
+__device__ __forceinline__ void dif(float (&re)[R], float (&im)[R]) {
+    constexpr float kS = 0.70710678118654752440f;
+#pragma unroll
+    for (int half = R / 2; half >= 1; half >>= 1) {
+#pragma unroll
+        for (int base = 0; base < R; base += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const int a = base + j, b = a + half;
+                const float ur = re[a], ui = im[a], vr = re[b], vi = im[b];
+                re[a] = ur + vr;
+                im[a] = ui + vi;
+                const float dr = ur - vr, di = ui - vi;
+                const int ang = j * (16 / half);  // twiddle angle in units of 2*pi/32
+                if (ang == 0) {
+                    re[b] = dr;
+                    im[b] = di;
+                } else if (ang == 8) {            // * (-i)
+                    re[b] = di;
+                    im[b] = -dr;
+                } else if (ang == 4) {
+                    re[b] = (dr + di) * kS;
+                    im[b] = (di - dr) * kS;
+                } else if (ang == 12) {
+                    re[b] = (di - dr) * kS;
+                    im[b] = -(dr + di) * kS;
+                } else {
+                    const float c = cos32(ang), s = sin32(ang);
+                    re[b] = dr * c + di * s;
+                    im[b] = di * c - dr * s;
+                }
+            }
+        }
+    }
+}
+
+// Orders this wave's LDS traffic: DS operations of one wave execute in issue
+// order, so all that is needed is that the compiler keeps the order too.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int R1>
+struct MelGeom {
+    static constexpr int NC = 64 * R1;
+    // row stride (complex) of transpose A chosen so that the 4 lane groups of
+    // stage 2a read disjoint bank halves
+    static constexpr int STRIDE_A = R1 == 8 ? 72 : (R1 == 16 ? 68 : 66);
+    static constexpr int STRIDE_B = 4 * R1 + 1;       // [q][4*R1 (+1 pad)]
+    static constexpr int SCR_A = R1 * STRIDE_A;
+    static constexpr int SCR_B = 16 * STRIDE_B;
+    static constexpr int SCR = (SCR_A > SCR_B ? (SCR_A > NC ? SCR_A : NC) : (SCR_B > NC ? SCR_B : NC));
+    static constexpr int NPAIR = R1 / 2 + 1;           // bins lane + 64*j <= NC/2
+};
+
+template <int R1, int WAVES, int FPB>
+__global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
+    using G = MelGeom<R1>;
+    constexpr int NC = G::NC;
+    constexpr int PS = FPB + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *scr_all = reinterpret_cast<float2 *>(smem);
+    float *P = reinterpret_cast<float *>(smem + sizeof(float2) * G::SCR * WAVES);
+    float *melw = P + (NC + 1) * PS;
+    int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    float2 *scr = scr_all + wave * G::SCR;
+
+    // ---- one-time per-workgroup / per-lane constants ------------------------
+    for (int i = tid; i < a.nnz; i += WAVES * 64) melw[i] = a.mel_w[i];
+    for (int i = tid; i < a.n_mels; i += WAVES * 64) {
+        melmeta[3 * i + 0] = a.mel_start[i];
+        melmeta[3 * i + 1] = a.mel_len[i];
+        melmeta[3 * i + 2] = a.mel_ptr[i];
+    }
+
+    float w0[R1], w1[R1];          // window taps of this lane's samples
+    float t1r[R1], t1i[R1];        // stage-1 twiddles  W_NC^(lane * k1), k1 = bitrev(p)
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        const int n = 64 * n1 + lane;
+        w0[n1] = a.win[2 * n];
+        w1[n1] = a.win[2 * n + 1];
+        const int k1 = bitrev<R1>(n1);
+        const float2 t = a.tw_nc[(lane * k1) & (NC - 1)];
+        t1r[n1] = t.x;
+        t1i[n1] = t.y;
+    }
+    const int q = lane & 15, g = lane >> 4;
+    float t2r[4], t2i[4];          // stage-2a twiddles W_64^(q*r), r = bitrev<4>(p)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float2 t = a.tw_nc[(q * bitrev<4>(p) * (NC / 64)) & (NC - 1)];
+        t2r[p] = t.x;
+        t2i[p] = t.y;
+    }
+    float t3r[G::NPAIR], t3i[G::NPAIR];   // untangle twiddles W_2NC^k, k = lane + 64 j
+#pragma unroll
+    for (int j = 0; j < G::NPAIR; ++j) {
+        const int k = lane + 64 * j;
+        const float2 t = a.tw_post[k <= NC / 2 ? k : 0];
+        t3r[j] = t.x;
+        t3i[j] = t.y;
+    }
+    __syncthreads();
+
+    for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const long clip = tile / a.tiles_per_clip;
+        const int f0 = static_cast<int>(tile - clip * a.tiles_per_clip) * FPB;
+        const float *yc = a.y + clip * a.n_samples;
+
+        for (int fi = wave; fi < FPB; fi += WAVES) {
+            const int t = f0 + fi;
+            if (t >= a.T) break;                       // wave-uniform
+            // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
+            float re[R1], im[R1];
+            const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                re[n1] = 0.f;
+                im[n1] = 0.f;
+                if (64 * n1 + 63 >= a.zlo && 64 * n1 < a.zhi) {   // wave-uniform
+                    const long s = s_base + 2 * (64 * n1 + lane);
+                    const float x0 = (s >= 0 && s < a.n_samples) ? yc[s] : 0.f;
+                    const float x1 = (s + 1 >= 0 && s + 1 < a.n_samples) ? yc[s + 1] : 0.f;
+                    re[n1] = x0 * w0[n1];
+                    im[n1] = x1 * w1[n1];
+                }
+            }
+            dif<R1>(re, im);
+#pragma unroll
+            for (int p = 0; p < R1; ++p) {             // twiddle, then transpose A: [k1][n2]
+                const float xr = re[p] * t1r[p] - im[p] * t1i[p];
+                const float xi = re[p] * t1i[p] + im[p] * t1r[p];
+                scr[bitrev<R1>(p) * G::STRIDE_A + lane] = make_float2(xr, xi);
+            }
+            wave_lds_fence();
+            // ---- stage 2a: radix-4 over p (n2 = 16 p + q), lane = (q, g) --------
+            float br[R1 / 4][4], bi[R1 / 4][4];
+#pragma unroll
+            for (int i = 0; i < R1 / 4; ++i) {
+                const int k1 = g * (R1 / 4) + i;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float2 v = scr[k1 * G::STRIDE_A + 16 * p + q];
+                    br[i][p] = v.x;
+                    bi[i][p] = v.y;
+                }
+            }
+            wave_lds_fence();                          // all reads before scratch is reused
+#pragma unroll
+            for (int i = 0; i < R1 / 4; ++i) {
+                const int k1 = g * (R1 / 4) + i;
+                dif<4>(br[i], bi[i]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {          // twiddle W_64^(q r), transpose B: [q][r*R1 + k1]
+                    const int r = bitrev<4>(p);
+                    const float xr = br[i][p] * t2r[p] - bi[i][p] * t2i[p];
+                    const float xi = br[i][p] * t2i[p] + bi[i][p] * t2r[p];
+                    scr[q * G::STRIDE_B + r * R1 + k1] = make_float2(xr, xi);
+                }
+            }
+            wave_lds_fence();
+            // ---- stage 2b: radix-16 over q, one butterfly per (r, k1) ----------
+            constexpr int NB = (4 * R1 + 63) / 64;
+            float cr[NB][16], ci[NB][16];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < 4 * R1) {
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq) {
+                        const float2 v = scr[qq * G::STRIDE_B + idx];
+                        cr[u][qq] = v.x;
+                        ci[u][qq] = v.y;
+                    }
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < 4 * R1) {
+                    dif<16>(cr[u], ci[u]);
+                    const int r = idx / R1, k1 = idx % R1;
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {     // natural order Z[k], k = k1 + R1 (r + 4 s)
+                        const int s = bitrev<16>(p);
+                        scr[k1 + R1 * (r + 4 * s)] = make_float2(cr[u][p], ci[u][p]);
+                    }
+                }
+            }
+            wave_lds_fence();
+            // ---- untangle real spectrum, power, into P[bin][fi] ----------------
+            // X[k] = E + W^k O, X[NC-k] = conj(E - W^k O), E = (Z[k] + conj Z[NC-k]) / 2,
+            // O = -i (Z[k] - conj Z[NC-k]) / 2
+#pragma unroll
+            for (int j = 0; j < G::NPAIR; ++j) {
+                const int k = lane + 64 * j;
+                if (k <= NC / 2) {
+                    const float2 za = scr[k];
+                    const float2 zb = scr[(NC - k) & (NC - 1)];
+                    const float er = 0.5f * (za.x + zb.x), ei = 0.5f * (za.y - zb.y);
+                    const float oR = 0.5f * (za.y + zb.y), oI = -0.5f * (za.x - zb.x);
+                    const float tr = oR * t3r[j] - oI * t3i[j];
+                    const float ti = oR * t3i[j] + oI * t3r[j];
+                    const float ar = er + tr, ai = ei + ti;
+                    const float cr2 = er - tr, ci2 = ei - ti;
+                    P[k * PS + fi] = ar * ar + ai * ai;
+                    P[(NC - k) * PS + fi] = cr2 * cr2 + ci2 * ci2;
+                }
+            }
+            wave_lds_fence();                          // scratch is reused by the next frame
+        }
+        __syncthreads();
+
+        // ---- sparse mel projection: lanes = (filter, frame) ----------------------
+        constexpr int MPW = 64 / FPB;                  // filters per wave pass
+        const int fl = lane % FPB, ml = lane / FPB;
+        const int nvalid = min(FPB, a.T - f0);
+        for (int m0 = wave * MPW; m0 < a.n_mels; m0 += WAVES * MPW) {
+            const int m = m0 + ml;
+            const bool ok = m < a.n_mels;
+            const int start = ok ? melmeta[3 * m + 0] : 0;
+            const int len = ok ? melmeta[3 * m + 1] : 0;
+            const int ptr = ok ? melmeta[3 * m + 2] : 0;
+            float acc = 0.f;
+            for (int i = 0; i < len; ++i) acc += melw[ptr + i] * P[(start + i) * PS + fl];
+            if (ok && fl < nvalid) {
+                if (a.flags & SEDMI_MEL_LOG) acc = 10.0f * log10f(fmaxf(acc, 1e-10f));
+                if (a.flags & SEDMI_MEL_NORMALISE) acc = (acc - a.mean[m]) * a.istd[m];
+                a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + f0 + fl] = acc;
+            }
+        }
+        __syncthreads();                               // P is overwritten by the next tile
+    }
+}
+
+template <int R1, int WAVES, int FPB>
+size_t mel_lds_bytes(int n_mels, int nnz) {
+    using G = MelGeom<R1>;
+    return sizeof(float2) * G::SCR * WAVES + sizeof(float) * (G::NC + 1) * (FPB + 1) +
+           sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 3 * n_mels;
+}
+
+// float64 -> per-bin statistics for the optional normalisation stage
+__global__ __launch_bounds__(256) void mel_stats_kernel(const float *mel, long n_clips, int n_mels, long T,
+                                                        double *sum, double *sumsq) {
+    // one workgroup per (mel bin, clip slab); lanes stride over frames
+    const int m = blockIdx.x;
+    double s = 0.0, s2 = 0.0;
+    for (long c = blockIdx.y; c < n_clips; c += gridDim.y) {
+        const float *row = mel + (c * n_mels + m) * T;
+        for (long t = threadIdx.x; t < T; t += blockDim.x) {
+            const double v = row[t];
+            s += v;
+            s2 += v * v;
+        }
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&sum[m], sh[0][0]);
+        atomicAdd(&sumsq[m], sh[1][0]);
+    }
+}
+
+// ---- host side: librosa's filterbank / window in double precision -----------
+
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+}  // namespace
+
+struct sedmi_mel_plan {
+    int sr, n_fft, win_length, hop, n_mels, n_bins;
+    int zlo, zhi, nnz;
+    int device, num_cus;
+    std::vector<float> fb_dense;   // host copy [n_mels, n_bins]
+    float *d_win = nullptr;
+    float2 *d_tw_nc = nullptr, *d_tw_post = nullptr;
+    int *d_start = nullptr, *d_len = nullptr, *d_ptr = nullptr;
+    float *d_w = nullptr;
+};
+
+extern "C" {
+
+int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_length, int hop_length,
+                          int n_mels) {
+    SEDMI_REQUIRE(out != nullptr, "plan pointer is null");
+    *out = nullptr;
+    SEDMI_REQUIRE(n_fft == 1024 || n_fft == 2048 || n_fft == 4096,
+                  "n_fft must be 1024, 2048 or 4096 (got %d)", n_fft);
+    SEDMI_REQUIRE(win_length > 0 && win_length <= n_fft, "win_length %d not in (0, n_fft]", win_length);
+    SEDMI_REQUIRE(hop_length > 0, "hop_length must be positive");
+    SEDMI_REQUIRE(n_mels > 0 && n_mels <= 1024, "n_mels %d not in (0, 1024]", n_mels);
+    SEDMI_REQUIRE(sr > 0, "sr must be positive");
+
+    auto *p = new sedmi_mel_plan();
+    p->sr = sr; p->n_fft = n_fft; p->win_length = win_length; p->hop = hop_length;
+    p->n_mels = n_mels; p->n_bins = 1 + n_fft / 2;
+    SEDMI_CHECK_HIP(hipGetDevice(&p->device));
+    hipDeviceProp_t prop;
+    SEDMI_CHECK_HIP(hipGetDeviceProperties(&prop, p->device));
+    p->num_cus = prop.multiProcessorCount;
+
+    // periodic Hann, centred (librosa.util.pad_center)
+    std::vector<float> win(n_fft, 0.f);
+    const int lpad = (n_fft - win_length) / 2;
+    for (int i = 0; i < win_length; ++i)
+        win[lpad + i] = static_cast<float>(0.5 - 0.5 * std::cos(2.0 * M_PI * i / win_length));
+    int lo = n_fft, hi = 0;
+    for (int i = 0; i < n_fft; ++i)
+        if (win[i] != 0.f) { lo = std::min(lo, i); hi = std::max(hi, i + 1); }
+    if (hi <= lo) { lo = 0; hi = 0; }
+    p->zlo = lo / 2;
+    p->zhi = (hi + 1) / 2;
+
+    const int NC = n_fft / 2;
+    std::vector<float2> tw_nc(NC), tw_post(NC / 2 + 1);
+    for (int j = 0; j < NC; ++j) {
+        const double ang = -2.0 * M_PI * j / NC;
+        tw_nc[j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+    }
+    for (int k = 0; k <= NC / 2; ++k) {
+        const double ang = -2.0 * M_PI * k / (2.0 * NC);
+        tw_post[k] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+    }
+
+    // librosa.filters.mel(sr, n_fft, n_mels): Slaney scale, Slaney norm, float32 result
+    const int nb = p->n_bins;
+    std::vector<double> mel_f(n_mels + 2);
+    const double mmin = hz_to_mel(0.0), mmax = hz_to_mel(sr / 2.0);
+    const double mstep = (mmax - mmin) / (n_mels + 1);       // numpy.linspace: i * step + start
+    for (int i = 0; i < n_mels + 2; ++i)
+        mel_f[i] = mel_to_hz(i == n_mels + 1 ? mmax : i * mstep + mmin);
+    p->fb_dense.assign(static_cast<size_t>(n_mels) * nb, 0.f);
+    std::vector<int> start(n_mels), len(n_mels), ptr(n_mels);
+    std::vector<float> wsp;
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k) {
+            const double f = (sr / 2.0) * k / (nb - 1);
+            const double lower = -(mel_f[i] - f) / fd0, upper = (mel_f[i + 2] - f) / fd1;
+            const double w = std::max(0.0, std::min(lower, upper));
+            // float32 triangle, then scaled by the float64 norm and rounded again (as numpy's
+            // in-place multiply of a float32 array by a float64 vector does)
+            const float w32 = static_cast<float>(static_cast<double>(static_cast<float>(w)) * enorm);
+            p->fb_dense[static_cast<size_t>(i) * nb + k] = w32;
+            if (w32 != 0.f) { if (first < 0) first = k; last = k; }
+        }
+        start[i] = first < 0 ? 0 : first;
+        len[i] = first < 0 ? 0 : last - first + 1;
+        ptr[i] = static_cast<int>(wsp.size());
+        for (int k = 0; k < len[i]; ++k) wsp.push_back(p->fb_dense[static_cast<size_t>(i) * nb + start[i] + k]);
+    }
+    p->nnz = static_cast<int>(wsp.size());
+
+    int rc;
+    if ((rc = sedmi::upload(&p->d_win, win)) || (rc = sedmi::upload(&p->d_tw_nc, tw_nc)) ||
+        (rc = sedmi::upload(&p->d_tw_post, tw_post)) || (rc = sedmi::upload(&p->d_start, start)) ||
+        (rc = sedmi::upload(&p->d_len, len)) || (rc = sedmi::upload(&p->d_ptr, ptr)) ||
+        (rc = sedmi::upload(&p->d_w, wsp))) {
+        sedmi_mel_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SEDMI_OK;
+}
+
+int sedmi_mel_plan_destroy(sedmi_mel_plan *p) {
+    if (!p) return SEDMI_OK;
+    (void)hipFree(p->d_win); (void)hipFree(p->d_tw_nc); (void)hipFree(p->d_tw_post);
+    (void)hipFree(p->d_start); (void)hipFree(p->d_len); (void)hipFree(p->d_ptr); (void)hipFree(p->d_w);
+    delete p;
+    return SEDMI_OK;
+}
+
+int64_t sedmi_mel_num_frames(const sedmi_mel_plan *p, int64_t n_samples) {
+    if (!p || n_samples < 0) return sedmi::set_error(SEDMI_EINVAL, "bad plan or n_samples");
+    return 1 + n_samples / p->hop;
+}
+
+int sedmi_mel_filterbank(const sedmi_mel_plan *p, float *host_out) {
+    SEDMI_REQUIRE(p && host_out, "null argument");
+    std::memcpy(host_out, p->fb_dense.data(), p->fb_dense.size() * sizeof(float));
+    return SEDMI_OK;
+}
+
+}  // extern "C"
+
+template <int R1, int WAVES, int FPB>
+static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
+    a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, FPB));
+    a.total_tiles = n_clips * a.tiles_per_clip;
+    const size_t lds = mel_lds_bytes<R1, WAVES, FPB>(p->n_mels, p->nnz);
+    SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
+    auto kern = mel_kernel<R1, WAVES, FPB>;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const long grid = std::min<long>(a.total_tiles, 2L * p->num_cus);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, a);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+extern "C" {
+
+int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, int64_t n_samples,
+                      int flags, const float *mean, const float *istd, float *out, void *stream) {
+    SEDMI_REQUIRE(p != nullptr, "plan is null");
+    SEDMI_REQUIRE(n_clips >= 0 && n_samples >= 0, "negative size");
+    SEDMI_REQUIRE((flags & ~(SEDMI_MEL_LOG | SEDMI_MEL_NORMALISE)) == 0, "unknown flags 0x%x", flags);
+    SEDMI_REQUIRE(!(flags & SEDMI_MEL_NORMALISE) || (mean && istd), "normalisation needs mean and istd");
+    if (n_clips == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(y && out, "null data pointer");
+    const int64_t T = 1 + n_samples / p->hop;
+    SEDMI_REQUIRE(T < (1LL << 31) && n_samples < (1LL << 40), "clip too long");
+    MelArgs a{};
+    a.y = y; a.n_samples = n_samples; a.T = static_cast<int>(T); a.hop = p->hop; a.n_fft = p->n_fft;
+    a.win = p->d_win; a.tw_nc = p->d_tw_nc; a.tw_post = p->d_tw_post; a.zlo = p->zlo; a.zhi = p->zhi;
+    a.n_mels = p->n_mels; a.mel_start = p->d_start; a.mel_len = p->d_len; a.mel_ptr = p->d_ptr;
+    a.mel_w = p->d_w; a.nnz = p->nnz; a.out = out; a.flags = flags; a.mean = mean; a.istd = istd;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (p->n_fft) {
+        case 1024: return launch_mel<8, 8, 16>(p, a, n_clips, s);
+        case 2048: return launch_mel<16, 8, 16>(p, a, n_clips, s);
+        default:   return launch_mel<32, 4, 8>(p, a, n_clips, s);
+    }
+}
+
+int sedmi_mel_stats_f64(const float *mel, int64_t n_clips, int n_mels, int64_t T, double *sum,
+                        double *sumsq, void *stream) {
+    SEDMI_REQUIRE(n_clips >= 0 && n_mels > 0 && T >= 0, "bad shape");
+    if (n_clips == 0 || T == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(mel && sum && sumsq, "null data pointer");
+    const unsigned slabs = static_cast<unsigned>(std::min<int64_t>(n_clips, 64));
+    hipLaunchKernelGGL(mel_stats_kernel, dim3(n_mels, slabs), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mel, n_clips, n_mels, T, sum, sumsq);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+}  // extern "C"
