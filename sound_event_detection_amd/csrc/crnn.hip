@@ -1,13 +1,752 @@
-// placeholder while the CRNN kernels are being written
+// Baseline CRNN eval-mode forward for gfx950 (MI355X).
+//
+// Stands in for CRNN.forward (nnet/CRNN.py:191-268) in the one configuration
+// the reference builds (training.py:207-212):
+//   7 x [Conv3x3(pad 1) -> BatchNorm2d(eps 1e-3, running stats) -> GLU
+//        (Linear_{C->C}(x) * sigmoid(x), nnet/CNN.py:5-16) -> AvgPool]
+//   -> squeeze / permute -> 2-layer bidirectional GRU(128) (nnet/RNN.py:19-30)
+//   -> sigmoid(Linear(256 -> n_class))                     (nnet/CRNN.py:142-143)
+//
+// Data layout in HBM: activations are channels-last, [clip][time][freq][chan]
+// float32, so the contraction index of every implicit GEMM is contiguous and
+// the last block's output [clip][time][1][128] already is the [B, T', C]
+// sequence the GRU reads (no permute kernel).
+//
+// Arithmetic is float32 end to end on the f32-input matrix instruction
+// v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain), so the only differences
+// to the reference's CPU result come from summation order.
+//
+// Kernels
+//   conv0_kernel      block 0 (1 input channel): VALU, one lane = one pooled
+//                     output position x 16 channels, weights as scalar operands.
+//   conv_mfma_kernel  blocks 1..6: implicit GEMM [positions] x [9*Cin] x [Cout].
+//                     A workgroup stages its input rows (+halo) once into LDS,
+//                     streams packed weights from L2 straight into registers
+//                     (no LDS round trip, no barrier in the main loop), then
+//                     runs the GLU's C x C linear as a second MFMA GEMM on the
+//                     BatchNorm output kept in LDS, multiplies by sigmoid(z)
+//                     from registers and average-pools pairs that sit in
+//                     adjacent accumulator registers of the same lane.
+//   linear_kernel     GRU input projections for all timesteps at once.
+//   gru_kernel        persistent recurrence: one workgroup = 32 clips x one
+//                     direction for all T' steps; W_hh (384x128) lives in
+//                     registers as MFMA B fragments for the whole kernel, h in
+//                     LDS (double buffered, one barrier per step), gates are
+//                     lane-local because each wave owns the r/z/n columns of
+//                     the same 32 hidden units.
+//   head_kernel       Linear(256 -> n_class) + sigmoid.
 #include "common.h"
-struct sedmi_crnn { int x; };
-extern "C" {
-int sedmi_crnn_create(sedmi_crnn **, const sedmi_crnn_weights *) { return sedmi::set_error(SEDMI_EINVAL, "CRNN not built yet"); }
-int sedmi_crnn_destroy(sedmi_crnn *) { return SEDMI_OK; }
-int64_t sedmi_crnn_out_frames(const sedmi_crnn *, int64_t) { return -1; }
-size_t sedmi_crnn_workspace_bytes(const sedmi_crnn *, int64_t, int64_t) { return 0; }
-int sedmi_crnn_forward_f32(const sedmi_crnn *, const float *, int64_t, int64_t, float *, void *, size_t, void *) { return SEDMI_EINVAL; }
-int sedmi_crnn_cnn_f32(const sedmi_crnn *, const float *, int64_t, int64_t, float *, void *, size_t, void *) { return SEDMI_EINVAL; }
-int sedmi_crnn_gru_f32(const sedmi_crnn *, const float *, int64_t, int64_t, float *, void *, size_t, void *) { return SEDMI_EINVAL; }
-int sedmi_crnn_head_f32(const sedmi_crnn *, const float *, int64_t, float *, void *) { return SEDMI_EINVAL; }
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
+__device__ __forceinline__ float tanhf_fast(float x) {
+    const float e = __expf(-2.0f * fabsf(x));
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf(t, x);
+}
+
+// row of accumulator register `reg` inside a 32x32 MFMA tile (column = lane & 31)
+__device__ __forceinline__ constexpr int acc_row(int reg, int half) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+
+// One wave's [64 x 32*NT] += A[64 x 8*kgroups] * B over `kgroups` groups of 8
+// contraction indices.  a0/a1: this lane's row of the two 32-row A tiles
+// (LDS, already offset by 4*(lane>>5)); bp: packed B [kgroup][n][8] in float4
+// units, already offset to this lane's (column, half); b_kg_stride in float4s.
+// Within a k-group lanes 0-31 carry k = 0..3 and lanes 32-63 k = 4..7, on both
+// operands, so each of the four MFMAs contracts two indices.
+template <int NT>
+__device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NT], const float *a0, const float *a1,
+                                          const float4 *bp, int kgroups, int b_kg_stride) {
+#pragma unroll 2
+    for (int kg = 0; kg < kgroups; ++kg) {
+        const float4 va0 = *reinterpret_cast<const float4 *>(a0 + kg * 8);
+        const float4 va1 = *reinterpret_cast<const float4 *>(a1 + kg * 8);
+        float4 vb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) vb[nt] = bp[kg * b_kg_stride + nt * 64];
+        const float fa0[4] = {va0.x, va0.y, va0.z, va0.w};
+        const float fa1[4] = {va1.x, va1.y, va1.z, va1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float fb = i == 0 ? vb[nt].x : (i == 1 ? vb[nt].y : (i == 2 ? vb[nt].z : vb[nt].w));
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i], fb, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i], fb, acc[1][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// block 0: 1 -> 16 channels, pool (2,2)
+// ---------------------------------------------------------------------------
+struct Conv0Params {
+    float w[16][9];      // conv weight [co][ky*3+kx]
+    float s[16], t[16];  // z = conv * s + t  (bias and BatchNorm folded)
+    float g[16][16];     // GLU linear weight [co][ci]
+    float gb[16];
+};
+
+__global__ __launch_bounds__(256) void conv0_kernel(const float *__restrict__ x, const Conv0Params *__restrict__ prm,
+                                                    float *__restrict__ y, long n_clips, int T, int F, int Tp) {
+    // x [clip][T][F], y [clip][Tp][F/2][16]
+    const int Fp = F / 2;
+    const long total = n_clips * Tp * Fp;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += 256L * gridDim.x) {
+        const int w2 = static_cast<int>(idx % Fp);
+        const long rest = idx / Fp;
+        const int h2 = static_cast<int>(rest % Tp);
+        const long b = rest / Tp;
+        const float *xb = x + b * static_cast<long>(T) * F;
+        float patch[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hr = 2 * h2 - 1 + r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int wc = 2 * w2 - 1 + c;
+                patch[r][c] = (hr >= 0 && hr < T && wc >= 0 && wc < F) ? xb[static_cast<long>(hr) * F + wc] : 0.f;
+            }
+        }
+        float z[4][16];
+#pragma unroll
+        for (int co = 0; co < 16; ++co) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = prm->w[co][ky * 3 + kx];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) a[p] = fmaf(patch[(p >> 1) + ky][(p & 1) + kx], wv, a[p]);
+                }
+            const float sc = prm->s[co], sh = prm->t[co];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) z[p][co] = fmaf(a[p], sc, sh);
+        }
+        float o[16];
+#pragma unroll
+        for (int co = 0; co < 16; ++co) {
+            float gl[4];
+            const float gb = prm->gb[co];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) gl[p] = gb;
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+                const float wv = prm->g[co][ci];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) gl[p] = fmaf(z[p][ci], wv, gl[p]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) sum += gl[p] * sigmoidf_fast(z[p][co]);
+            o[co] = 0.25f * sum;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(y + idx * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[v] = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// blocks 1..6: implicit-GEMM conv + BN + GLU + pool(1,2)
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT, int W>
+struct ConvGeom {
+    static constexpr int WN = COUT >= 64 ? 64 : COUT;   // columns per wave
+    static constexpr int NT = WN / 32;
+    static constexpr int WAVES_N = COUT / WN;
+    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int M = 64 * WAVES_M;               // positions per workgroup
+    static constexpr int TH = M / W;                     // rows (time steps) per workgroup
+    static constexpr int PS = CIN + 4;                   // LDS stride of one input position (floats)
+    static constexpr int TW = W + 2;
+    static constexpr int IN_FLOATS = (TH + 2) * TW * PS;
+    static constexpr int ZS = COUT + 4;
+    static constexpr int Z_FLOATS = M * ZS;
+    static constexpr int LDS_FLOATS = IN_FLOATS > Z_FLOATS ? IN_FLOATS : Z_FLOATS;
+    static constexpr int KG = CIN / 8;
+    static_assert(M % W == 0 && CIN % 8 == 0 && COUT % 32 == 0 && W % 2 == 0, "unsupported conv geometry");
+};
+
+template <int CIN, int COUT, int W>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(
+    const float *__restrict__ x,       // [clip][H][W][CIN]
+    const float4 *__restrict__ wp,     // packed conv weight [9][CIN/8][COUT][8]
+    const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // z = conv * s + t
+    const float4 *__restrict__ gp,     // packed GLU weight [COUT/8][COUT][8]
+    const float *__restrict__ gb,
+    float *__restrict__ y,             // [clip][H][W/2][COUT]
+    int H, int tiles_per_clip) {
+    using G = ConvGeom<CIN, COUT, W>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
+    const long clip = blockIdx.x / tiles_per_clip;
+    const int h0 = static_cast<int>(blockIdx.x % tiles_per_clip) * G::TH;
+    const float *xc = x + clip * static_cast<long>(H) * W * CIN;
+
+    // ---- stage input rows h0-1 .. h0+TH (zero outside the clip) with a zero column each side
+    constexpr int ROW_F4 = W * CIN / 4;
+    for (int i = tid; i < (G::TH + 2) * ROW_F4; i += 256) {
+        const int rr = i / ROW_F4, e = (i - rr * ROW_F4) * 4;
+        const int w = e / CIN, c = e - w * CIN;
+        const int hr = h0 - 1 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hr >= 0 && hr < H) v = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(hr) * W + w) * CIN + c);
+        *reinterpret_cast<float4 *>(lds + (rr * G::TW + 1 + w) * G::PS + c) = v;
+    }
+    for (int i = tid; i < (G::TH + 2) * 2 * (CIN / 4); i += 256) {
+        const int rr = i / (2 * (CIN / 4)), rem = i - rr * 2 * (CIN / 4);
+        const int side = rem / (CIN / 4), c = (rem - side * (CIN / 4)) * 4;
+        *reinterpret_cast<float4 *>(lds + (rr * G::TW + side * (W + 1)) * G::PS + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    // ---- main loop: 9 taps x CIN/8 k-groups, weights streamed from global/L2
+    f32x16 acc[2][G::NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int pos0 = 64 * wm + col32, pos1 = pos0 + 32;
+    const float *a0 = lds + ((pos0 / W) * G::TW + pos0 % W) * G::PS + 4 * half;
+    const float *a1 = lds + ((pos1 / W) * G::TW + pos1 % W) * G::PS + 4 * half;
+    const int ncol = wn * G::WN + col32;
+    const float4 *bp = wp + ncol * 2 + half;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * G::TW + (tap % 3)) * G::PS;
+        mma_block<G::NT>(acc, a0 + toff, a1 + toff, bp + tap * G::KG * COUT * 2, G::KG, COUT * 2);
+    }
+
+    // ---- BatchNorm affine, stash z for the GLU contraction
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+        const float sc = bn_s[ncol + 32 * nt], sh = bn_t[ncol + 32 * nt];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], sc, sh);
+    }
+    __syncthreads();                                   // every wave is done with the input tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[(64 * wm + 32 * mt + acc_row(r, half)) * G::ZS + ncol + 32 * nt] = acc[mt][nt][r];
+    __syncthreads();
+
+    // ---- GLU: lin = z . Wg^T (+ bias), out = lin * sigmoid(z), then average adjacent freq pairs
+    f32x16 lin[2][G::NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lin[mt][nt][r] = 0.f;
+    mma_block<G::NT>(lin, lds + pos0 * G::ZS + 4 * half, lds + pos1 * G::ZS + 4 * half, gp + ncol * 2 + half,
+                     COUT / 8, COUT * 2);
+
+    float *yc = y + clip * static_cast<long>(H) * (W / 2) * COUT;
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+        const float bias = gb[ncol + 32 * nt];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float o0 = (lin[mt][nt][r] + bias) * sigmoidf_fast(acc[mt][nt][r]);
+                const float o1 = (lin[mt][nt][r + 1] + bias) * sigmoidf_fast(acc[mt][nt][r + 1]);
+                const int pos = 64 * wm + 32 * mt + acc_row(r, half);     // even position, partner is pos + 1
+                const int hr = h0 + pos / W;
+                if (hr < H)
+                    yc[(static_cast<long>(hr) * (W / 2) + (pos % W) / 2) * COUT + ncol + 32 * nt] = 0.5f * (o0 + o1);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C[M][N] = A[M][K] . B + bias, B packed [K/8][N][8]; N % 128 == 0, K % 128 == 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ A, const float4 *__restrict__ bpk,
+                                                     const float *__restrict__ bias, float *__restrict__ C, long M,
+                                                     int N, int K) {
+    constexpr int KC = 128, AS = KC + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = static_cast<long>(blockIdx.x) * 128;
+    const int n0 = blockIdx.y * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const int ncol = n0 + wn * 64 + col32;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        if (k0) __syncthreads();
+        for (int i = tid; i < 128 * (KC / 4); i += 256) {
+            const int r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) v = *reinterpret_cast<const float4 *>(A + (m0 + r) * K + k0 + c);
+            *reinterpret_cast<float4 *>(lds + r * AS + c) = v;
+        }
+        __syncthreads();
+        const float *a0 = lds + (64 * wm + col32) * AS + 4 * half;
+        mma_block<2>(acc, a0, a0 + 32 * AS, bpk + (static_cast<long>(k0 / 8) * N + ncol) * 2 + half, KC / 8, N * 2);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = bias[ncol + 32 * nt];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
+                if (row < M) C[row * N + ncol + 32 * nt] = acc[mt][nt][r] + bv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GRU recurrence, hidden size 128, one workgroup = 32 clips x 1 direction
+// ---------------------------------------------------------------------------
+constexpr int GRU_H = 128;
+constexpr int GRU_NB = 32;           // clips per workgroup (= MFMA M)
+constexpr int GRU_HS = GRU_H + 4;    // LDS row stride of h
+
+__global__ __launch_bounds__(256, 1) void gru_kernel(
+    const float *__restrict__ gi,      // [clip][T][2][3H]: W_ih x + b_ih (+ b_hh for r, z)
+    const float4 *__restrict__ whh,    // packed [2][H/8][3H][8]
+    const float *__restrict__ bhn,     // [2][H]
+    float *__restrict__ out,           // [clip][T][2H]
+    long n_clips, int T) {
+    __shared__ __attribute__((aligned(16))) float hs[2][GRU_NB * GRU_HS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int dir = blockIdx.y;
+    const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;
+    const int j = 32 * wave + col32;                  // hidden unit owned by this lane
+
+    // W_hh fragments for gates r, z, n of unit j: resident for the whole kernel
+    float4 wreg[3][GRU_H / 8];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kg = 0; kg < GRU_H / 8; ++kg)
+            wreg[g][kg] = whh[((static_cast<long>(dir) * (GRU_H / 8) + kg) * (3 * GRU_H) + g * GRU_H + j) * 2 + half];
+    const float b_hn = bhn[dir * GRU_H + j];
+
+    for (int i = tid; i < 2 * GRU_NB * GRU_HS; i += 256) (&hs[0][0])[i] = 0.f;
+    float hprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hprev[r] = 0.f;
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        // this step's input projections (consumed after the MFMA loop)
+        float gir[16], giz[16], gin[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long b = b0 + acc_row(r, half);
+            gir[r] = giz[r] = gin[r] = 0.f;
+            if (b < n_clips) {
+                const float *p = gi + ((b * T + t) * 2 + dir) * (3 * GRU_H) + j;
+                gir[r] = p[0];
+                giz[r] = p[GRU_H];
+                gin[r] = p[2 * GRU_H];
+            }
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        const float *arow = &hs[cur][col32 * GRU_HS + 4 * half];
+#pragma unroll
+        for (int kg = 0; kg < GRU_H / 8; ++kg) {
+            const float4 va = *reinterpret_cast<const float4 *>(arow + kg * 8);
+            const float fa[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float4 wv = wreg[g][kg];
+                    const float fb = i == 0 ? wv.x : (i == 1 ? wv.y : (i == 2 ? wv.z : wv.w));
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb, acc[g], 0, 0, 0);
+                }
+        }
+        float *hnext = &hs[cur ^ 1][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float rg = sigmoidf_fast(gir[r] + acc[0][r]);
+            const float zg = sigmoidf_fast(giz[r] + acc[1][r]);
+            const float ng = tanhf_fast(fmaf(rg, acc[2][r] + b_hn, gin[r]));
+            const float hn = fmaf(zg, hprev[r] - ng, ng);          // (1 - z) * n + z * h
+            hprev[r] = hn;
+            const int row = acc_row(r, half);
+            hnext[row * GRU_HS + j] = hn;
+            const long b = b0 + row;
+            if (b < n_clips) out[(b * T + t) * (2 * GRU_H) + dir * GRU_H + j] = hn;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// strong head: probs = sigmoid(x . Wd^T + bd), x [rows][256]
+// ---------------------------------------------------------------------------
+constexpr int HEAD_K = 2 * GRU_H;
+constexpr int HEAD_ROWS = 64;
+
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, const float *__restrict__ wd,
+                                                   const float *__restrict__ bd, float *__restrict__ probs,
+                                                   long n_rows, int n_cls) {
+    extern __shared__ __attribute__((aligned(16))) float head_lds[];
+    float (*xs)[HEAD_K + 1] = reinterpret_cast<float (*)[HEAD_K + 1]>(head_lds);
+    const int tid = threadIdx.x;
+    const long r0 = static_cast<long>(blockIdx.x) * HEAD_ROWS;
+    for (int i = tid; i < HEAD_ROWS * HEAD_K; i += 256) {
+        const int r = i / HEAD_K, k = i - r * HEAD_K;
+        xs[r][k] = r0 + r < n_rows ? x[(r0 + r) * HEAD_K + k] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: weights become scalar loads
+    for (int c = cg; c < n_cls; c += 4) {
+        const float *wrow = wd + c * HEAD_K;
+        float a0 = bd[c], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < HEAD_K; k += 4) {
+            a0 = fmaf(xs[r][k], wrow[k], a0);
+            a1 = fmaf(xs[r][k + 1], wrow[k + 1], a1);
+            a2 = fmaf(xs[r][k + 2], wrow[k + 2], a2);
+            a3 = fmaf(xs[r][k + 3], wrow[k + 3], a3);
+        }
+        if (r0 + r < n_rows) probs[(r0 + r) * n_cls + c] = sigmoidf_fast((a0 + a1) + (a2 + a3));
+    }
+}
+
+// pack value(k, n) into [K/8][N][8]
+template <typename F>
+std::vector<float> pack_kn8(int K, int N, F value) {
+    std::vector<float> out(static_cast<size_t>(K) * N);
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) out[(static_cast<size_t>(k / 8) * N + n) * 8 + (k % 8)] = value(k, n);
+    return out;
+}
+
+constexpr int kCnnChunk = 512;      // clips per pass through the conv stack (bounds the scratch)
+
+}  // namespace
+
+struct sedmi_crnn {
+    int n_class = 0, device = 0, num_cus = 0;
+    Conv0Params *d_c0 = nullptr;
+    float *d_wp[SEDMI_CRNN_LAYERS] = {};   // packed conv weights (blocks 1..6)
+    float *d_s[SEDMI_CRNN_LAYERS] = {}, *d_t[SEDMI_CRNN_LAYERS] = {};
+    float *d_gp[SEDMI_CRNN_LAYERS] = {}, *d_gb[SEDMI_CRNN_LAYERS] = {};
+    float *d_wih[2] = {}, *d_bi[2] = {}, *d_whh[2] = {}, *d_bhn[2] = {};
+    float *d_wd = nullptr, *d_bd = nullptr;
+};
+
+namespace {
+
+constexpr int kFilters[SEDMI_CRNN_LAYERS] = {16, 32, 64, 128, 128, 128, 128};
+
+template <int CIN, int COUT, int W>
+int launch_conv(const sedmi_crnn *m, int layer, const float *x, float *y, long n_clips, int H, hipStream_t s) {
+    using G = ConvGeom<CIN, COUT, W>;
+    const int tiles = static_cast<int>(sedmi::ceil_div(H, G::TH));
+    const size_t lds = sizeof(float) * G::LDS_FLOATS;
+    auto kern = conv_mfma_kernel<CIN, COUT, W>;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_clips * tiles)), dim3(256), lds, s, x,
+                       reinterpret_cast<const float4 *>(m->d_wp[layer]), m->d_s[layer], m->d_t[layer],
+                       reinterpret_cast<const float4 *>(m->d_gp[layer]), m->d_gb[layer], y, H, tiles);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+struct Scratch {
+    float *actA, *actB, *seq, *gi, *rec0, *rec1;
+    size_t bytes;
+};
+
+Scratch carve(void *ws, long n_clips, long Tp, bool with_cnn, bool with_gru) {
+    Scratch sc{};
+    size_t off = 0;
+    auto take = [&](size_t n_floats) {
+        float *p = reinterpret_cast<float *>(static_cast<char *>(ws) + off);
+        off += sedmi::align_up(n_floats * sizeof(float), 256);
+        return p;
+    };
+    const long ch = std::min<long>(n_clips, kCnnChunk);
+    if (with_cnn) {
+        sc.actA = take(static_cast<size_t>(ch) * Tp * 1024);
+        sc.actB = take(static_cast<size_t>(ch) * Tp * 1024);
+    }
+    if (with_gru) {
+        sc.seq = take(static_cast<size_t>(n_clips) * Tp * GRU_H);
+        sc.gi = take(static_cast<size_t>(n_clips) * Tp * 6 * GRU_H);
+        sc.rec0 = take(static_cast<size_t>(n_clips) * Tp * 2 * GRU_H);
+        sc.rec1 = take(static_cast<size_t>(n_clips) * Tp * 2 * GRU_H);
+    }
+    sc.bytes = off;
+    return sc;
+}
+
+int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float *seq, float *actA, float *actB,
+            hipStream_t s) {
+    const int Tp = T / 2;
+    for (long c0 = 0; c0 < n_clips; c0 += kCnnChunk) {
+        const long nc = std::min<long>(kCnnChunk, n_clips - c0);
+        const float *x = feats + c0 * static_cast<long>(T) * 128;
+        const long total0 = nc * Tp * 64;
+        const unsigned grid0 = static_cast<unsigned>(std::min<long>(sedmi::ceil_div(total0, 256), 1L << 20));
+        hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
+        SEDMI_CHECK_LAUNCH();
+        int rc;
+        if ((rc = launch_conv<16, 32, 64>(m, 1, actA, actB, nc, Tp, s))) return rc;
+        if ((rc = launch_conv<32, 64, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
+        if ((rc = launch_conv<64, 128, 16>(m, 3, actA, actB, nc, Tp, s))) return rc;
+        if ((rc = launch_conv<128, 128, 8>(m, 4, actB, actA, nc, Tp, s))) return rc;
+        if ((rc = launch_conv<128, 128, 4>(m, 5, actA, actB, nc, Tp, s))) return rc;
+        if ((rc = launch_conv<128, 128, 2>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
+    }
+    return SEDMI_OK;
+}
+
+int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *gi, float *rec0, float *rec1,
+            hipStream_t s) {
+    const long rows = n_clips * Tp;
+    const size_t lds = sizeof(float) * 128 * 132;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const float *in = seq;
+    float *outs[2] = {rec0, rec1};
+    for (int layer = 0; layer < 2; ++layer) {
+        const int K = layer == 0 ? GRU_H : 2 * GRU_H;
+        hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6), dim3(256), lds,
+                           s, in, reinterpret_cast<const float4 *>(m->d_wih[layer]), m->d_bi[layer], gi, rows,
+                           6 * GRU_H, K);
+        SEDMI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gru_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2), dim3(256), 0,
+                           s, gi, reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer], outs[layer],
+                           n_clips, Tp);
+        SEDMI_CHECK_LAUNCH();
+        in = outs[layer];
+    }
+    return SEDMI_OK;
+}
+
+int check_shape(const sedmi_crnn *m, int64_t n_clips, int64_t T) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(n_clips >= 0 && T >= 0, "negative size");
+    SEDMI_REQUIRE(T < (1 << 30) && n_clips < (1LL << 31), "shape too large");
+    return SEDMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
+    SEDMI_REQUIRE(out && w, "null argument");
+    *out = nullptr;
+    SEDMI_REQUIRE(w->n_freq == 128, "only n_freq = 128 is supported (got %d)", w->n_freq);
+    SEDMI_REQUIRE(w->hidden == GRU_H, "only GRU hidden size 128 is supported (got %d)", w->hidden);
+    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
+    for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
+        SEDMI_REQUIRE(w->filters[i] == kFilters[i], "filters[%d] = %d: only 16,32,64,128,128,128,128 is supported",
+                      i, w->filters[i]);
+        SEDMI_REQUIRE(w->pool_f[i] == 2 && w->pool_t[i] == (i == 0 ? 2 : 1),
+                      "pooling of block %d must be (%d,2)", i, i == 0 ? 2 : 1);
+        SEDMI_REQUIRE(w->conv_w[i] && w->conv_b[i] && w->bn_w[i] && w->bn_b[i] && w->bn_mean[i] && w->bn_var[i] &&
+                          w->glu_w[i] && w->glu_b[i], "null weight pointer in block %d", i);
+    }
+    for (int l = 0; l < 2; ++l)
+        for (int d = 0; d < 2; ++d)
+            SEDMI_REQUIRE(w->gru_w_ih[l][d] && w->gru_w_hh[l][d] && w->gru_b_ih[l][d] && w->gru_b_hh[l][d],
+                          "null GRU weight pointer (layer %d, direction %d)", l, d);
+    SEDMI_REQUIRE(w->dense_w && w->dense_b, "null head weight pointer");
+
+    auto *m = new sedmi_crnn();
+    m->n_class = w->n_class;
+    int rc = SEDMI_OK;
+    auto fail = [&](int code) { sedmi_crnn_destroy(m); return code; };
+    if (hipGetDevice(&m->device) != hipSuccess) return fail(sedmi::set_error(SEDMI_EHIP, "hipGetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->device) != hipSuccess)
+        return fail(sedmi::set_error(SEDMI_EHIP, "hipGetDeviceProperties failed"));
+    m->num_cus = prop.multiProcessorCount;
+
+    // BatchNorm (eval) as z = conv_nobias * s + t, s = gamma / sqrt(var + eps), t = (bias - mean) * s + beta
+    std::vector<float> s[SEDMI_CRNN_LAYERS], t[SEDMI_CRNN_LAYERS];
+    for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
+        const int co = kFilters[i];
+        s[i].resize(co); t[i].resize(co);
+        for (int c = 0; c < co; ++c) {
+            const float sc = w->bn_w[i][c] / std::sqrt(w->bn_var[i][c] + w->bn_eps);
+            s[i][c] = sc;
+            t[i][c] = (w->conv_b[i][c] - w->bn_mean[i][c]) * sc + w->bn_b[i][c];
+        }
+    }
+    {
+        Conv0Params p;
+        for (int co = 0; co < 16; ++co) {
+            for (int k = 0; k < 9; ++k) p.w[co][k] = w->conv_w[0][co * 9 + k];
+            p.s[co] = s[0][co]; p.t[co] = t[0][co]; p.gb[co] = w->glu_b[0][co];
+            for (int ci = 0; ci < 16; ++ci) p.g[co][ci] = w->glu_w[0][co * 16 + ci];
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&m->d_c0), sizeof(p)) != hipSuccess ||
+            hipMemcpy(m->d_c0, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(sedmi::set_error(SEDMI_EHIP, "uploading block 0 parameters failed"));
+    }
+    for (int i = 1; i < SEDMI_CRNN_LAYERS; ++i) {
+        const int ci = kFilters[i - 1], co = kFilters[i];
+        std::vector<float> wp;
+        wp.reserve(static_cast<size_t>(9) * ci * co);
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *src = w->conv_w[i];
+            auto blk = pack_kn8(ci, co, [&](int k, int n) { return src[(static_cast<size_t>(n) * ci + k) * 9 + tap]; });
+            wp.insert(wp.end(), blk.begin(), blk.end());
+        }
+        const float *gsrc = w->glu_w[i];
+        auto gp = pack_kn8(co, co, [&](int k, int n) { return gsrc[static_cast<size_t>(n) * co + k]; });
+        std::vector<float> gb(w->glu_b[i], w->glu_b[i] + co);
+        if ((rc = sedmi::upload(&m->d_wp[i], wp)) || (rc = sedmi::upload(&m->d_s[i], s[i])) ||
+            (rc = sedmi::upload(&m->d_t[i], t[i])) || (rc = sedmi::upload(&m->d_gp[i], gp)) ||
+            (rc = sedmi::upload(&m->d_gb[i], gb)))
+            return fail(rc);
+    }
+    for (int l = 0; l < 2; ++l) {
+        const int K = l == 0 ? GRU_H : 2 * GRU_H;
+        // input projection for both directions: columns [dir][gate][unit]
+        auto wih = pack_kn8(K, 6 * GRU_H, [&](int k, int n) {
+            return w->gru_w_ih[l][n / (3 * GRU_H)][static_cast<size_t>(n % (3 * GRU_H)) * K + k];
+        });
+        std::vector<float> bi(6 * GRU_H), bhn(2 * GRU_H), whh;
+        for (int d = 0; d < 2; ++d) {
+            for (int n = 0; n < 3 * GRU_H; ++n)
+                bi[d * 3 * GRU_H + n] = w->gru_b_ih[l][d][n] + (n < 2 * GRU_H ? w->gru_b_hh[l][d][n] : 0.f);
+            for (int n = 0; n < GRU_H; ++n) bhn[d * GRU_H + n] = w->gru_b_hh[l][d][2 * GRU_H + n];
+            const float *src = w->gru_w_hh[l][d];
+            auto blk = pack_kn8(GRU_H, 3 * GRU_H, [&](int k, int n) { return src[static_cast<size_t>(n) * GRU_H + k]; });
+            whh.insert(whh.end(), blk.begin(), blk.end());
+        }
+        if ((rc = sedmi::upload(&m->d_wih[l], wih)) || (rc = sedmi::upload(&m->d_bi[l], bi)) ||
+            (rc = sedmi::upload(&m->d_whh[l], whh)) || (rc = sedmi::upload(&m->d_bhn[l], bhn)))
+            return fail(rc);
+    }
+    {
+        std::vector<float> wd(w->dense_w, w->dense_w + static_cast<size_t>(w->n_class) * HEAD_K);
+        std::vector<float> bd(w->dense_b, w->dense_b + w->n_class);
+        if ((rc = sedmi::upload(&m->d_wd, wd)) || (rc = sedmi::upload(&m->d_bd, bd))) return fail(rc);
+    }
+    *out = m;
+    return SEDMI_OK;
+}
+
+int sedmi_crnn_destroy(sedmi_crnn *m) {
+    if (!m) return SEDMI_OK;
+    (void)hipFree(m->d_c0);
+    for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
+        (void)hipFree(m->d_wp[i]); (void)hipFree(m->d_s[i]); (void)hipFree(m->d_t[i]);
+        (void)hipFree(m->d_gp[i]); (void)hipFree(m->d_gb[i]);
+    }
+    for (int l = 0; l < 2; ++l) {
+        (void)hipFree(m->d_wih[l]); (void)hipFree(m->d_bi[l]); (void)hipFree(m->d_whh[l]); (void)hipFree(m->d_bhn[l]);
+    }
+    (void)hipFree(m->d_wd); (void)hipFree(m->d_bd);
+    delete m;
+    return SEDMI_OK;
+}
+
+int64_t sedmi_crnn_out_frames(const sedmi_crnn *m, int64_t T) {
+    if (!m || T < 0) return sedmi::set_error(SEDMI_EINVAL, "bad model or T");
+    return T / 2;
+}
+
+size_t sedmi_crnn_workspace_bytes(const sedmi_crnn *m, int64_t n_clips, int64_t T) {
+    if (!m || n_clips <= 0 || T < 2) return 0;
+    return carve(nullptr, n_clips, T / 2, true, true).bytes;
+}
+
+int sedmi_crnn_cnn_f32(const sedmi_crnn *m, const float *feats, int64_t n_clips, int64_t T, float *seq, void *ws,
+                       size_t ws_bytes, void *stream) {
+    int rc = check_shape(m, n_clips, T);
+    if (rc) return rc;
+    if (n_clips == 0 || T < 2) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && seq && ws, "null data pointer");
+    Scratch sc = carve(ws, n_clips, T / 2, true, false);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    return run_cnn(m, feats, n_clips, static_cast<int>(T), seq, sc.actA, sc.actB, static_cast<hipStream_t>(stream));
+}
+
+int sedmi_crnn_gru_f32(const sedmi_crnn *m, const float *seq, int64_t n_clips, int64_t Tp, float *rec, void *ws,
+                       size_t ws_bytes, void *stream) {
+    int rc = check_shape(m, n_clips, Tp);
+    if (rc) return rc;
+    if (n_clips == 0 || Tp == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(seq && rec && ws, "null data pointer");
+    Scratch sc = carve(ws, n_clips, Tp, false, true);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    return run_gru(m, seq, n_clips, static_cast<int>(Tp), sc.gi, sc.rec0, rec, static_cast<hipStream_t>(stream));
+}
+
+int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, float *probs, void *stream) {
+    SEDMI_REQUIRE(m != nullptr && n_rows >= 0, "bad argument");
+    if (n_rows == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(rec && probs, "null data pointer");
+    const size_t lds = sizeof(float) * HEAD_ROWS * (HEAD_K + 1);
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
+                       m->n_class);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int sedmi_crnn_forward_f32(const sedmi_crnn *m, const float *feats, int64_t n_clips, int64_t T, float *probs,
+                           void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_shape(m, n_clips, T);
+    if (rc) return rc;
+    if (n_clips == 0 || T < 2) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && probs && ws, "null data pointer");
+    const int Tp = static_cast<int>(T / 2);
+    Scratch sc = carve(ws, n_clips, Tp, true, true);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = run_cnn(m, feats, n_clips, static_cast<int>(T), sc.seq, sc.actA, sc.actB, s))) return rc;
+    if ((rc = run_gru(m, sc.seq, n_clips, Tp, sc.gi, sc.rec0, sc.rec1, s))) return rc;
+    return sedmi_crnn_head_f32(m, sc.rec1, n_clips * Tp, probs, stream);
+}
+
+}  // extern "C"

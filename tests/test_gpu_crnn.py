@@ -1,0 +1,112 @@
+"""HIP CRNN vs outputs of the reference's CNN / BidirectionalGRU classes
+(tests/golden/crnn_*.npz) and vs the CPU oracle (needs an MI355X)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn as ocrnn
+from sound_event_detection_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3          # north-star tolerance on frame probabilities (absolute)
+
+
+def _model(seed, ncls):
+    from sound_event_detection_amd.nnet import CRNN
+    # the constructor call of training.py:207-212
+    m = CRNN(dropout=0.5, rnn_layers=2, n_in_channel=1, nclass=ncls, attention=True, n_RNN_cell=128,
+             activation='glu', rnn_type='BGRU', kernel_size=[3] * 7, padding=[1] * 7, stride=[1] * 7,
+             nb_filters=[16, 32, 64, 128, 128, 128, 128], pooling=[[2, 2]] + [[1, 2]] * 6, dropout_recurrent=0)
+    sd = synth.synth_crnn_state_dict(seed, nclass=ncls)
+    missing = m.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(m.state_dict().keys()) == list(sd.keys())          # the reference's 83 keys, in order
+    m.eval()
+    return m.cuda(), sd
+
+
+@pytest.mark.parametrize("fname,seed,ncls", [("crnn_seed0.npz", 0, 10), ("crnn_seed3_small.npz", 3, 6)])
+def test_stages_match_reference_golden(golden_dir, fname, seed, ncls):
+    g = np.load(os.path.join(golden_dir, fname))
+    m, _ = _model(seed, ncls)
+    x = torch.from_numpy(g["feats"]).cuda()
+    seq, rec, probs = m.forward_stages(x)
+    ref_seq = np.transpose(g["cnn_out"][..., 0], (0, 2, 1))        # [B,C,T',1] -> [B,T',C]
+    scale = np.abs(ref_seq).max()
+    assert np.abs(seq.cpu().numpy() - ref_seq).max() < 1e-5 * scale
+    assert np.abs(rec.cpu().numpy() - g["gru_out"]).max() < 1e-4
+    assert np.abs(probs.cpu().numpy() - g["probs"]).max() < PROB_TOL
+    full = m(x)
+    assert torch.equal(full, probs)
+    assert np.abs(full.cpu().numpy() - g["probs"]).max() < 1e-4     # well inside the 1e-3 budget
+
+
+def test_gru_stage_alone_matches_reference_golden(golden_dir):
+    """Feeds the reference's own conv output to the HIP GRU, so that conv
+    rounding cannot mask or cause a recurrence error."""
+    from sound_event_detection_amd import _lib
+    g = np.load(os.path.join(golden_dir, "crnn_seed0.npz"))
+    m, _ = _model(0, 10)
+    seq = torch.from_numpy(np.ascontiguousarray(np.transpose(g["cnn_out"][..., 0], (0, 2, 1)))).cuda()
+    B, Tp, _ = seq.shape
+    handle = m._get_handle(seq.device)
+    lib = _lib.lib()
+    ws_bytes = lib.sedmi_crnn_workspace_bytes(handle, B, 2 * Tp)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    rec = torch.empty((B, Tp, 256), device="cuda")
+    _lib.check(lib.sedmi_crnn_gru_f32(handle, _lib.ptr(seq), B, Tp, _lib.ptr(rec), _lib.ptr(ws), ws_bytes,
+                                      _lib.stream_ptr(seq.device)))
+    assert np.abs(rec.cpu().numpy() - g["gru_out"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("B,T", [(1, 501), (5, 501), (33, 64), (70, 9), (3, 2)])
+def test_forward_matches_oracle_on_ragged_shapes(B, T):
+    m, sd = _model(1, 10)
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + T))
+    x = (rng.gamma(0.5, 2.0, (B, T, 128))).astype(np.float32)       # power-like, heavy tailed
+    got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ocrnn.crnn_forward(sd, torch.from_numpy(x)).numpy()
+    assert got.shape == want.shape == (B, T // 2, 10)
+    assert np.abs(got - want).max() < PROB_TOL
+
+
+def test_batch_independence_and_determinism():
+    """Clips are independent (they shard across GPUs): a clip's output must not
+    depend on its batch position or on its neighbours, and must repeat exactly."""
+    m, _ = _model(2, 10)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(67, 501, 128, device="cuda", generator=g) * 3
+    a = m(x)
+    b = m(x)
+    assert torch.equal(a, b)
+    perm = torch.randperm(67, device="cuda", generator=g)
+    c = m(x[perm])
+    assert torch.equal(c, a[perm])
+    assert torch.equal(m(x[10:11]), a[10:11])
+
+
+def test_reload_weights_rebuilds_handle():
+    m, sd = _model(4, 10)
+    x = torch.rand(2, 101, 128, device="cuda")
+    a = m(x)
+    sd2 = synth.synth_crnn_state_dict(5, nclass=10)
+    m.load_state_dict(sd2)
+    b = m(x)
+    want = ocrnn.crnn_forward(sd2, x.cpu()).numpy()
+    assert not torch.equal(a, b)
+    assert np.abs(b.cpu().numpy() - want).max() < PROB_TOL
+
+
+def test_errors_are_loud():
+    from sound_event_detection_amd import _lib
+    m, _ = _model(0, 10)
+    with pytest.raises(_lib.SedmiError):
+        m(torch.zeros(1, 501, 128))                 # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 501, 64, device="cuda"))
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 501, 128, device="cuda"))
