@@ -199,6 +199,27 @@ int sedmi_decode_events(const float *p, int64_t total_frames, int n_class,
 int sedmi_confusion_counts(const float *p, const float *labels, int64_t n_rows, int n_class,
                            float thr, int apply_sigmoid, int64_t *counts, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Per-kernel timing (no counterpart in the reference; it exists so that a
+ * benchmark can quote each kernel's duration and its algorithmic FLOP / byte
+ * rate from HIP events recorded on the very stream the kernels run on).
+ * While enabled, every kernel launch of this library is bracketed by two
+ * events.  sedmi_profile_collect waits for the recorded events (it
+ * synchronises), sums them per kernel name and clears the record.
+ * Process-wide; enable/collect from one thread at a time.
+ * ------------------------------------------------------------------------ */
+typedef struct sedmi_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double ms;        /* summed device time of those launches           */
+    double flops;     /* summed algorithmic floating-point operations   */
+    double bytes;     /* summed algorithmic bytes (inputs read once + outputs written once) */
+} sedmi_kernel_stat;
+
+int sedmi_profile_enable(int on);
+/* Returns the number of entries written (<= capacity) or a negative code. */
+int sedmi_profile_collect(sedmi_kernel_stat *out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

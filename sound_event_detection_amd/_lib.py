@@ -36,6 +36,11 @@ class CrnnWeights(C.Structure):
     ]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); must list every symbol include/sedmi.h declares
 _VP, _I64, _SZ, _F, _I = C.c_void_p, C.c_int64, C.c_size_t, C.c_float, C.c_int
 SIGNATURES = {
@@ -61,6 +66,8 @@ SIGNATURES = {
     "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,
                                  _I64, _VP, _VP, _SZ, _VP]),
     "sedmi_confusion_counts": (_I, [_VP, _VP, _I64, _I, _F, _I, _VP, _VP]),
+    "sedmi_profile_enable": (_I, [_I]),
+    "sedmi_profile_collect": (_I, [C.POINTER(KernelStat), _I]),
 }
 
 _lib = None
@@ -74,6 +81,9 @@ def lib() -> C.CDLL:
             raise SedmiError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C sound_event_detection_amd/csrc`). There is no CPU fallback.")
+        # torch first: its bundled HIP runtime must be the one this process uses, or the tensors'
+        # device pointers and streams would belong to a different runtime instance than the kernels
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the symbol is missing
@@ -98,3 +108,15 @@ def stream_ptr(device) -> C.c_void_p:
     """The hipStream_t torch is currently enqueueing on for ``device``."""
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().sedmi_profile_enable(int(bool(on))))
+
+
+def profile_collect():
+    """[{name, launches, ms, flops, bytes}] summed per kernel since enable; synchronises."""
+    buf = (KernelStat * 64)()
+    n = check(lib().sedmi_profile_collect(buf, 64))
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), ms=float(buf[i].ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]

@@ -44,6 +44,22 @@ int upload(T **dev, const std::vector<T> &host) {
     return SEDMI_OK;
 }
 
+// Optional per-launch timing (see sedmi_profile_enable in sedmi.h).
+bool profile_enabled();
+void profile_begin(const char *name, hipStream_t stream, double flops, double bytes);
+void profile_end(hipStream_t stream);
+
+struct ProfileScope {
+    hipStream_t stream;
+    bool on;
+    ProfileScope(const char *name, hipStream_t s, double flops, double bytes) : stream(s), on(profile_enabled()) {
+        if (on) profile_begin(name, s, flops, bytes);
+    }
+    ~ProfileScope() {
+        if (on) profile_end(stream);
+    }
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
 
 namespace {
 
@@ -486,6 +487,11 @@ int launch_conv(const sedmi_crnn *m, int layer, const float *x, float *y, long n
     auto kern = conv_mfma_kernel<CIN, COUT, W>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    static const std::string name = "conv_mfma<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
+                                    std::to_string(W) + ">";
+    const double pos = static_cast<double>(n_clips) * H * W;
+    sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
+                             pos * 4.0 * (CIN + COUT / 2.0));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_clips * tiles)), dim3(256), lds, s, x,
                        reinterpret_cast<const float4 *>(m->d_wp[layer]), m->d_s[layer], m->d_t[layer],
                        reinterpret_cast<const float4 *>(m->d_gp[layer]), m->d_gb[layer], y, H, tiles);
@@ -529,7 +535,12 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         const float *x = feats + c0 * static_cast<long>(T) * 128;
         const long total0 = nc * Tp * 64;
         const unsigned grid0 = static_cast<unsigned>(std::min<long>(sedmi::ceil_div(total0, 256), 1L << 20));
-        hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
+        {
+            const double pos = static_cast<double>(nc) * (2.0 * Tp) * 128;
+            sedmi::ProfileScope prof("conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
+                                     4.0 * nc * (static_cast<double>(T) * 128 + Tp * 64.0 * 16));
+            hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
+        }
         SEDMI_CHECK_LAUNCH();
         int rc;
         if ((rc = launch_conv<16, 32, 64>(m, 1, actA, actB, nc, Tp, s))) return rc;
@@ -552,13 +563,21 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
     float *outs[2] = {rec0, rec1};
     for (int layer = 0; layer < 2; ++layer) {
         const int K = layer == 0 ? GRU_H : 2 * GRU_H;
-        hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6), dim3(256), lds,
-                           s, in, reinterpret_cast<const float4 *>(m->d_wih[layer]), m->d_bi[layer], gi, rows,
-                           6 * GRU_H, K);
+        {
+            sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj<128>" : "gru_input_proj<256>", s,
+                                     2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
+            hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6), dim3(256),
+                               lds, s, in, reinterpret_cast<const float4 *>(m->d_wih[layer]), m->d_bi[layer], gi,
+                               rows, 6 * GRU_H, K);
+        }
         SEDMI_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gru_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2), dim3(256), 0,
-                           s, gi, reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer], outs[layer],
-                           n_clips, Tp);
+        {
+            sedmi::ProfileScope prof("gru_kernel", s, 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
+                                     4.0 * rows * (6.0 * GRU_H + 2.0 * GRU_H));
+            hipLaunchKernelGGL(gru_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2), dim3(256),
+                               0, s, gi, reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer],
+                               outs[layer], n_clips, Tp);
+        }
         SEDMI_CHECK_LAUNCH();
         in = outs[layer];
     }
@@ -727,6 +746,8 @@ int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, f
     const size_t lds = sizeof(float) * HEAD_ROWS * (HEAD_K + 1);
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    sedmi::ProfileScope prof("head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
+                             4.0 * n_rows * (HEAD_K + m->n_class));
     hipLaunchKernelGGL(head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
                        static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
                        m->n_class);

@@ -202,16 +202,26 @@ int sedmi_decode_events(const float *p, int64_t total_frames, int n_class, const
     const int half = median_win / 2;
     const long long *ss = reinterpret_cast<const long long *>(seg_start);
     const long long *sc = reinterpret_cast<const long long *>(seg_cutoff);
+    const double dbytes = 4.0 * total_frames * n_class;
+    {
+    sedmi::ProfileScope prof("decode_count", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));
+    }
     SEDMI_CHECK_LAUNCH();
+    {
+    sedmi::ProfileScope prof("decode_scan", s, 0.0, 12.0 * pairs);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, counts, pairs, offsets,
                        reinterpret_cast<long long *>(n_events));
+    }
     SEDMI_CHECK_LAUNCH();
+    {
+    sedmi::ProfileScope prof("decode_write", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));
+    }
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

@@ -504,6 +504,11 @@ static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStre
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const long grid = std::min<long>(a.total_tiles, 2L * p->num_cus);
+    const double frames = static_cast<double>(n_clips) * a.T;
+    sedmi::ProfileScope prof("mel_kernel", stream,
+                             frames * (2.5 * p->n_fft * std::log2(static_cast<double>(p->n_fft)) + 3.0 * p->n_bins +
+                                       2.0 * p->nnz),
+                             4.0 * (static_cast<double>(n_clips) * a.n_samples + frames * p->n_mels));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, a);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;

@@ -82,13 +82,18 @@ def crnn_state_dict_spec(nclass: int = 10, n_in_channel: int = 1,
     return spec
 
 
-def synth_crnn_state_dict(seed: int = 0, nclass: int = 10, head_gain: float = 6.0):
+def synth_crnn_state_dict(seed: int = 0, nclass: int = 10, head_gain: float = 4.0):
     """Deterministic CRNN weights as an ordered dict of CPU float32 tensors.
 
-    Fan-in scaled uniform weights; BatchNorm statistics near (0, 1) except the
-    first layer, whose running_var is sized to the power-mel input range; the
-    strong head is scaled by ``head_gain`` so that frame probabilities spread
-    on both sides of 0.5 instead of sitting at 0.5 +- 0.02.
+    Fan-in scaled uniform weights.  BatchNorm running statistics are what
+    training would have left behind on these clips: near (0, 1) for blocks
+    1..6, and (0.8, 190) for block 0, whose input is the heavy-tailed power mel
+    spectrogram (no log in the reference: std ~13, bursts up to several
+    hundred).  That keeps every block's output O(1) and the network as well
+    conditioned as a trained one: float32 and float64 evaluations of it agree
+    to ~1e-5 on the probabilities.  The strong head is scaled by ``head_gain``
+    so that frame probabilities spread on both sides of 0.5 instead of sitting
+    at 0.5 +- 0.02.
     """
     rng = np.random.Generator(np.random.PCG64(977 + int(seed)))
     sd = {}
@@ -104,9 +109,9 @@ def synth_crnn_state_dict(seed: int = 0, nclass: int = 10, head_gain: float = 6.
             elif leaf == "bias":
                 v = rng.uniform(-0.1, 0.1, shape)
             elif leaf == "running_mean":
-                v = rng.uniform(-0.1, 0.1, shape) + (0.2 if first else 0.0)
+                v = rng.uniform(-0.1, 0.1, shape) + (0.8 if first else 0.0)
             else:  # running_var
-                v = rng.uniform(0.8, 1.2, shape) * (9.0 if first else 1.0)
+                v = rng.uniform(0.8, 1.2, shape) * (190.0 if first else 1.0)
         elif leaf.startswith("bias"):
             v = rng.uniform(-0.1, 0.1, shape)
         else:
