@@ -1,0 +1,58 @@
+"""Sharding helpers and the two exchange steps on a 2-rank gloo group (CPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sound_event_detection_amd import parallel
+
+
+def test_shard_range_covers_everything_in_order():
+    for n in (0, 1, 7, 8, 9, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            parts = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for (a, b), (c, d) in zip(parts, parts[1:]):
+                assert b == c and a <= b
+            assert max(b - a for a, b in parts) <= -(-n // world) if n else True
+
+
+def test_shard_recordings_keeps_recordings_whole():
+    clips = [3, 1, 1, 24, 2, 2, 2, 9, 1, 5]
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            a, b, ca, cb = parallel.shard_recordings(clips, r, world)
+            assert ca == sum(clips[:a]) and cb == sum(clips[:b])
+            seen += list(range(a, b))
+        assert seen == list(range(len(clips)))
+
+
+def _worker(rank, world, port, n_total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        full = torch.rand(n_total, 25, 10, generator=g)
+        lo, hi = parallel.shard_range(n_total, rank, world)
+        got = parallel.all_gather_probs(full[lo:hi].clone(), n_total)
+        assert torch.equal(got, full)
+        mel = torch.rand(n_total, 16, 50, generator=g, dtype=torch.float64)
+        loc = mel[lo:hi]
+        mean, std = parallel.all_reduce_mel_stats(loc.sum((0, 2)), (loc * loc).sum((0, 2)), float(loc.shape[0] * 50))
+        assert torch.allclose(mean, mel.mean((0, 2)), rtol=1e-12)
+        assert torch.allclose(std, mel.std((0, 2), unbiased=False), rtol=1e-9)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_steps_on_two_gloo_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 7), nprocs=2, join=True)
