@@ -131,6 +131,16 @@ typedef struct sedmi_crnn_weights {
  * layout its kernel reads, and uploads the result to the current device. */
 int sedmi_crnn_create(sedmi_crnn **model, const sedmi_crnn_weights *w);
 int sedmi_crnn_destroy(sedmi_crnn *model);
+/* Arithmetic of the conv blocks 1..6 (block 0, the GRU and the head are always float32):
+ *   SEDMI_PRECISION_F32        v_mfma_f32_32x32x2_f32, exact float32 products;
+ *   SEDMI_PRECISION_SPLIT_F16  every float32 operand split into two f16 halves (22 significand
+ *                              bits), three f16 MFMAs per product, float32 accumulation: about
+ *                              4x the relative rounding of float32 at ~5x the matrix-core rate.
+ *                              Activations of magnitude >= 65504 saturate in this mode.
+ * The default is SEDMI_PRECISION_SPLIT_F16. */
+#define SEDMI_PRECISION_F32        0
+#define SEDMI_PRECISION_SPLIT_F16  1
+int sedmi_crnn_set_precision(sedmi_crnn *model, int precision);
 /* Output frames for T input frames (product of the time poolings, floored). */
 int64_t sedmi_crnn_out_frames(const sedmi_crnn *model, int64_t T);
 /* Scratch bytes sedmi_crnn_forward_f32 needs for a batch of n_clips x T. */

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libsedmi.so")
 SEDMI_MEL_LOG = 1
 SEDMI_MEL_NORMALISE = 2
 CRNN_LAYERS = 7
+PRECISION_F32 = 0
+PRECISION_SPLIT_F16 = 1
 
 
 class SedmiError(RuntimeError):
@@ -55,6 +57,7 @@ SIGNATURES = {
     "sedmi_mel_stats_f64": (_I, [_VP, _I64, _I, _I64, _VP, _VP, _VP]),
     "sedmi_crnn_create": (_I, [C.POINTER(_VP), C.POINTER(CrnnWeights)]),
     "sedmi_crnn_destroy": (_I, [_VP]),
+    "sedmi_crnn_set_precision": (_I, [_VP, _I]),
     "sedmi_crnn_out_frames": (_I64, [_VP, _I64]),
     "sedmi_crnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
     "sedmi_crnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),

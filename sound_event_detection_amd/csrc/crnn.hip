@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(
     }
 }
 
+#include "conv_split.h"
+
 // ---------------------------------------------------------------------------
 // C[M][N] = A[M][K] . B + bias, B packed [K/8][N][8]; N % 128 == 0, K % 128 == 0
 // ---------------------------------------------------------------------------
@@ -471,6 +473,10 @@ struct sedmi_crnn {
     float *d_wp[SEDMI_CRNN_LAYERS] = {};   // packed conv weights (blocks 1..6)
     float *d_s[SEDMI_CRNN_LAYERS] = {}, *d_t[SEDMI_CRNN_LAYERS] = {};
     float *d_gp[SEDMI_CRNN_LAYERS] = {}, *d_gb[SEDMI_CRNN_LAYERS] = {};
+    // split-f16 variants (blocks 1..6): packed hi/lo weights, scales with the power-of-two weight scale undone
+    uint16_t *d_wps[SEDMI_CRNN_LAYERS] = {}, *d_gps[SEDMI_CRNN_LAYERS] = {};
+    float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {};
+    int precision = SEDMI_PRECISION_SPLIT_F16;
     float *d_wih[2] = {}, *d_bi[2] = {}, *d_whh[2] = {}, *d_bhn[2] = {};
     float *d_wd = nullptr, *d_bd = nullptr;
 };
@@ -497,6 +503,55 @@ int launch_conv(const sedmi_crnn *m, int layer, const float *x, float *y, long n
                        reinterpret_cast<const float4 *>(m->d_gp[layer]), m->d_gb[layer], y, H, tiles);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
+}
+
+template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
+int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, long n_clips, int H, hipStream_t s) {
+    using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH>;
+    const int tiles = static_cast<int>(sedmi::ceil_div(H, G::TH));
+    const size_t lds = G::LDS_BYTES;
+    auto kern = conv_split_kernel<CIN, COUT, W, WAVES_M, MT, CCH>;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    static const std::string name = "conv_split<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
+                                    std::to_string(W) + ">";
+    const double pos = static_cast<double>(n_clips) * H * W;
+    sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
+                             pos * 4.0 * (CIN + COUT / 2.0));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_clips * tiles)), dim3(256), lds, s, x,
+                       reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_t[layer],
+                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gb[layer], y, H, tiles);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+// float32 -> [ksteps][2 planes][N][16] f16 (hi, lo) of value(kstep, k16, n) * 2^scale_exp
+template <typename F>
+std::vector<uint16_t> pack_split(int ksteps, int N, int scale_exp, F value) {
+    std::vector<uint16_t> out(static_cast<size_t>(ksteps) * 2 * N * 16);
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < 16; ++k) {
+                const float v = std::ldexp(value(ks, k, n), scale_exp);
+                const _Float16 hi = static_cast<_Float16>(v);
+                const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
+                uint16_t hb, lb;
+                std::memcpy(&hb, &hi, 2);
+                std::memcpy(&lb, &lo, 2);
+                out[((static_cast<size_t>(ks) * 2 + 0) * N + n) * 16 + k] = hb;
+                out[((static_cast<size_t>(ks) * 2 + 1) * N + n) * 16 + k] = lb;
+            }
+    return out;
+}
+
+// exponent S such that max|w| * 2^S lies in [64, 128)
+int split_scale_exp(const float *w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int e;
+    std::frexp(mx, &e);
+    return 7 - e;
 }
 
 struct Scratch {
@@ -543,6 +598,15 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         }
         SEDMI_CHECK_LAUNCH();
         int rc;
+        if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
+            if ((rc = launch_conv_split<16, 32, 64, 4, 2, 16>(m, 1, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<64, 128, 16, 2, 4, 64>(m, 3, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 8, 2, 4, 64>(m, 4, actB, actA, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 4, 2, 4, 64>(m, 5, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 2, 2, 4, 32>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
+            continue;
+        }
         if ((rc = launch_conv<16, 32, 64>(m, 1, actA, actB, nc, Tp, s))) return rc;
         if ((rc = launch_conv<32, 64, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
         if ((rc = launch_conv<64, 128, 16>(m, 3, actA, actB, nc, Tp, s))) return rc;
@@ -659,6 +723,28 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
         const float *gsrc = w->glu_w[i];
         auto gp = pack_kn8(co, co, [&](int k, int n) { return gsrc[static_cast<size_t>(n) * co + k]; });
         std::vector<float> gb(w->glu_b[i], w->glu_b[i] + co);
+        {
+            // split-f16 copies: k-step order [chunk][tap][k-step in chunk], channels 16 per k-step
+            static const int kChunk[SEDMI_CRNN_LAYERS] = {0, 16, 32, 64, 64, 64, 32};
+            const int cch = kChunk[i], ks_per = cch / 16, nchunk = ci / cch;
+            const float *src = w->conv_w[i];
+            const int S = split_scale_exp(src, static_cast<size_t>(co) * ci * 9);
+            auto wps = pack_split(9 * ci / 16, co, S, [&](int kidx, int k16, int n) {
+                const int ks = kidx % ks_per, tap = (kidx / ks_per) % 9, c = kidx / (ks_per * 9);
+                (void)nchunk;
+                const int ch = c * cch + ks * 16 + k16;
+                return src[(static_cast<size_t>(n) * ci + ch) * 9 + tap];
+            });
+            const int Sg = split_scale_exp(gsrc, static_cast<size_t>(co) * co);
+            auto gps = pack_split(co / 16, co, Sg, [&](int kidx, int k16, int n) {
+                return gsrc[static_cast<size_t>(n) * co + kidx * 16 + k16];
+            });
+            std::vector<float> ss(co), gs(co, std::ldexp(1.0f, -Sg));
+            for (int c = 0; c < co; ++c) ss[c] = std::ldexp(s[i][c], -S);
+            if ((rc = sedmi::upload(&m->d_wps[i], wps)) || (rc = sedmi::upload(&m->d_gps[i], gps)) ||
+                (rc = sedmi::upload(&m->d_ss[i], ss)) || (rc = sedmi::upload(&m->d_gs[i], gs)))
+                return fail(rc);
+        }
         if ((rc = sedmi::upload(&m->d_wp[i], wp)) || (rc = sedmi::upload(&m->d_s[i], s[i])) ||
             (rc = sedmi::upload(&m->d_t[i], t[i])) || (rc = sedmi::upload(&m->d_gp[i], gp)) ||
             (rc = sedmi::upload(&m->d_gb[i], gb)))
@@ -698,12 +784,21 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
     for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
         (void)hipFree(m->d_wp[i]); (void)hipFree(m->d_s[i]); (void)hipFree(m->d_t[i]);
         (void)hipFree(m->d_gp[i]); (void)hipFree(m->d_gb[i]);
+        (void)hipFree(m->d_wps[i]); (void)hipFree(m->d_gps[i]); (void)hipFree(m->d_ss[i]); (void)hipFree(m->d_gs[i]);
     }
     for (int l = 0; l < 2; ++l) {
         (void)hipFree(m->d_wih[l]); (void)hipFree(m->d_bi[l]); (void)hipFree(m->d_whh[l]); (void)hipFree(m->d_bhn[l]);
     }
     (void)hipFree(m->d_wd); (void)hipFree(m->d_bd);
     delete m;
+    return SEDMI_OK;
+}
+
+int sedmi_crnn_set_precision(sedmi_crnn *m, int precision) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(precision == SEDMI_PRECISION_F32 || precision == SEDMI_PRECISION_SPLIT_F16,
+                  "unknown precision %d", precision);
+    m->precision = precision;
     return SEDMI_OK;
 }
 

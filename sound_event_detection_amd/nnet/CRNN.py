@@ -15,6 +15,7 @@ CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -72,6 +73,9 @@ class CRNN(nn.Module):
         self._handle = None
         self._handle_sig = None
         self._handle_fin = None
+        # arithmetic of conv blocks 1..6: "split_f16" (default; float32 operands as two f16 halves on the
+        # f16 matrix cores, float32-grade accuracy) or "f32" (exact float32 MFMA, ~4x slower)
+        self.conv_precision = os.environ.get("SEDMI_CONV_PRECISION", "split_f16")
 
     # ------------------------------------------------------------------ handle
     def _signature(self):
@@ -89,9 +93,16 @@ class CRNN(nn.Module):
                 "the HIP path implements the CRNN configuration of training.py:207-212 only: 1 input channel, "
                 "filters 16,32,64,128,128,128,128, 3x3/1/1 convs, pooling (2,2),(1,2)x6, 2-layer BGRU(128)")
 
+    def _apply_precision(self):
+        modes = {"f32": _lib.PRECISION_F32, "split_f16": _lib.PRECISION_SPLIT_F16}
+        if self.conv_precision not in modes:
+            raise ValueError(f"conv_precision must be one of {sorted(modes)}")
+        _lib.check(_lib.lib().sedmi_crnn_set_precision(self._handle, modes[self.conv_precision]))
+
     def _get_handle(self, device):
         sig = (device.index, self._signature())
         if self._handle is not None and self._handle_sig == sig:
+            self._apply_precision()
             return self._handle
         self._check_supported()
         self._release()
@@ -124,6 +135,7 @@ class CRNN(nn.Module):
             _lib.check(_lib.lib().sedmi_crnn_create(C.byref(handle), C.byref(w)), "sedmi_crnn_create")
         self._handle, self._handle_sig = handle, sig
         self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_crnn_destroy, handle)
+        self._apply_precision()
         return handle
 
     def _release(self):
