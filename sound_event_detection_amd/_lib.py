@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsedmi.so")
+LIB_PATH = os.environ.get("SEDMI_LIB_PATH") or os.path.join(_HERE, "libsedmi.so")
 
 SEDMI_MEL_LOG = 1
 SEDMI_MEL_NORMALISE = 2

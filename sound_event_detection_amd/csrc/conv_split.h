@@ -19,9 +19,21 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 __device__ __forceinline__ void split_f16(float x, _Float16 &hi, _Float16 &lo) {
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     hi = static_cast<_Float16>(x);
     lo = static_cast<_Float16>(x - static_cast<float>(hi));
+}
+
+// Two values at once with the packed round-toward-zero convert: hi is then truncated rather than
+// rounded, which costs one bit (hi + lo still carries >= 21 significand bits) and halves the
+// conversion instructions.  Returns the packed f16 pairs as 32-bit words.
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned &hi, unsigned &lo) {
+    x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - static_cast<float>(h[0]), x1 - static_cast<float>(h[1]));
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 // CIN/COUT/W: layer geometry (input width W, output width W/2).
@@ -37,7 +49,9 @@ struct SplitGeom {
     static constexpr int PSB = CCH * 2 + 16;             // bytes per position per plane (16 B pad)
     static constexpr int PLANE_A = (TH + 2) * TW * PSB;
     static constexpr int ZSB = COUT * 2 + 16;
-    static constexpr int PLANE_Z = M * ZSB;
+    static constexpr int MG = MT >= 2 ? 2 : 1;           // m-tiles per wave that go through the GLU together
+    static constexpr int ZROWS = WAVES_M * 32 * MG;      // rows of the z planes (one GLU phase)
+    static constexpr int PLANE_Z = ZROWS * ZSB;
     static constexpr int LDS_BYTES = 2 * (PLANE_A > PLANE_Z ? PLANE_A : PLANE_Z);
     static constexpr int NCHUNK = CIN / CCH;
     static constexpr int KS = CCH / 16;                  // k-steps per tap per chunk
@@ -46,20 +60,30 @@ struct SplitGeom {
                       COUT % 32 == 0 && W % 2 == 0 && LDS_BYTES <= 160 * 1024, "unsupported split-conv geometry");
 };
 
-// One k-step (16 contraction indices) of a wave's (MT x NT) tile block.
-// ah/al: LDS byte pointers of this lane's row in the hi / lo planes for each m-tile,
-// already offset by 16*(lane>>5).  b: packed weights for this k-step, [plane][N][16] f16,
-// as uint4 (16 B) units, already offset to (column, half) of n-tile 0.
-template <int MT, int NT, int N>
-__device__ __forceinline__ void split_kstep(f32x16 (&acc)[MT][NT], const char *(&ah)[MT],
-                                            const char *(&al)[MT], int a_off, const uint4 *b) {
-    f16x8 vah[MT], val[MT], vbh[NT], vbl[NT];
+// B (weight) fragments of one k-step for NT column tiles: hi and lo planes.
+template <int NT>
+struct SplitB {
+    f16x8 h[NT], l[NT];
+};
+
+// b: packed weights of one k-step, [plane][N][16] f16 as uint4 (16 B) units, already offset to
+// this lane's (column, half) of n-tile 0.
+template <int NT, int N>
+__device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const uint4 h = b[nt * 64], l = b[N * 2 + nt * 64];
-        vbh[nt] = __builtin_bit_cast(f16x8, h);
-        vbl[nt] = __builtin_bit_cast(f16x8, l);
+        f.h[nt] = __builtin_bit_cast(f16x8, h);
+        f.l[nt] = __builtin_bit_cast(f16x8, l);
     }
+}
+
+// One k-step: A fragments (this lane's rows in the hi / lo LDS planes, pointers already offset by
+// 16*(lane>>5)) are read here; the weights come in registers.
+template <int MT, int NT>
+__device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
+                                           int a_off, const SplitB<NT> &b) {
+    f16x8 vah[MT], val[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         vah[mt] = *reinterpret_cast<const f16x8 *>(ah[mt] + a_off);
@@ -69,14 +93,39 @@ __device__ __forceinline__ void split_kstep(f32x16 (&acc)[MT][NT], const char *(
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val[mt], vbh[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], vbl[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], vbh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.l[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
         }
 }
 
+// acc += A . B over NSTEPS consecutive k-steps.  The weights of step i+1 are requested from L2
+// before the MFMAs of step i issue (their latency is several hundred cycles); the LDS operands are
+// read at the head of their own step and covered by the second wave on the SIMD.
+// a_off(i) = LDS byte offset of step i relative to ah/al; B advances by N*4 uint4 per step.
+template <int MT, int NT, int N, int NSTEPS, typename AOff>
+__device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
+                                           const uint4 *b, AOff a_off) {
+    constexpr int BS = N * 4;       // uint4 per k-step: 2 planes x N columns x 32 B
+    SplitB<NT> b0, b1;
+    split_load_b<NT, N>(b0, b);
+#pragma unroll
+    for (int i = 0; i < NSTEPS; i += 2) {
+        // sched_barrier pins "request the next step's weights, then run this step": left alone, the
+        // scheduler sinks every load to just above its first use and the wave stalls on each one
+        if (i + 1 < NSTEPS) split_load_b<NT, N>(b1, b + (i + 1) * BS);
+        __builtin_amdgcn_sched_barrier(0);
+        split_step<MT, NT>(acc, ah, al, a_off(i), b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < NSTEPS) split_load_b<NT, N>(b0, b + (i + 2) * BS);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < NSTEPS) split_step<MT, NT>(acc, ah, al, a_off(i + 1), b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
-__global__ __launch_bounds__(256) void conv_split_kernel(
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const float *__restrict__ x,       // [clip][H][W][CIN] f32
     const uint4 *__restrict__ wp,      // packed split weights [KSTEPS][2][COUT][16] f16, order chunk/tap/k
     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // z = acc * s + t (weight scale folded into s)
@@ -124,35 +173,43 @@ __global__ __launch_bounds__(256) void conv_split_kernel(
     const uint4 *bp = wp + ncol * 2 + half;
 
     constexpr int ROW_F4 = W * CCH / 4;
+    constexpr int STAGE_F4 = (G::TH + 2) * ROW_F4;
+    constexpr int NLD = (STAGE_F4 + 255) / 256;
     for (int c = 0; c < G::NCHUNK; ++c) {
-        if (c) __syncthreads();                        // every wave is done reading the previous chunk
-        for (int i = tid; i < (G::TH + 2) * ROW_F4; i += 256) {
+        // all of this thread's loads are issued before the first one is consumed, so the chunk costs
+        // one memory latency, not NLD of them
+        float4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
             const int rr = i / ROW_F4, e = (i - rr * ROW_F4) * 4;
             const int w = e / CCH, ch = e - w * CCH;
             const int hr = h0 - 1 + rr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hr >= 0 && hr < H)
-                v = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(hr) * W + w) * CIN + c * CCH + ch);
-            f16x4 hi, lo;
-            _Float16 a, b;
-            split_f16(v.x, a, b); hi[0] = a; lo[0] = b;
-            split_f16(v.y, a, b); hi[1] = a; lo[1] = b;
-            split_f16(v.z, a, b); hi[2] = a; lo[2] = b;
-            split_f16(v.w, a, b); hi[3] = a; lo[3] = b;
-            const int off = (rr * G::TW + 1 + w) * G::PSB + ch * 2;
-            *reinterpret_cast<f16x4 *>(plane_h + off) = hi;
-            *reinterpret_cast<f16x4 *>(plane_l + off) = lo;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < STAGE_F4 && hr >= 0 && hr < H)
+                v[j] = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(hr) * W + w) * CIN + c * CCH + ch);
         }
-        __syncthreads();
+        if (c) __syncthreads();                        // every wave is done reading the previous chunk
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * G::TW + (tap % 3)) * G::PSB;
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                const int kidx = (c * 9 + tap) * G::KS + ks;
-                split_kstep<MT, NT, COUT>(acc, ah, al, toff + ks * 32, bp + static_cast<long>(kidx) * (COUT * 4));
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int rr = i / ROW_F4, e = (i - rr * ROW_F4) * 4;
+            const int w = e / CCH, ch = e - w * CCH;
+            uint2 hi, lo;
+            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
+            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+            if (i < STAGE_F4) {
+                const int off = (rr * G::TW + 1 + w) * G::PSB + ch * 2;
+                *reinterpret_cast<uint2 *>(plane_h + off) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + off) = lo;
             }
         }
+        __syncthreads();
+        split_gemm<MT, NT, COUT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4),
+                                            [](int i) {
+                                                const int tap = i / G::KS, ks = i % G::KS;
+                                                return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
+                                            });
     }
 
     // ---- BatchNorm affine; z stays in the accumulators and goes to LDS as hi/lo planes
@@ -164,27 +221,28 @@ __global__ __launch_bounds__(256) void conv_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], sc, sh);
     }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                _Float16 hi, lo;
-                split_f16(acc[mt][nt][r], hi, lo);
-                const int off = (32 * MT * wm + 32 * mt + acc_row(r, half)) * G::ZSB + (ncol + 32 * nt) * 2;
-                *reinterpret_cast<_Float16 *>(plane_h + off) = hi;
-                *reinterpret_cast<_Float16 *>(plane_l + off) = lo;
-            }
-    __syncthreads();
 
-    // ---- GLU linear on the z planes, two m-tiles at a time, then gate, pool, store
+    // ---- GLU linear, MG m-tiles per wave at a time: z -> hi/lo planes in LDS (they alias the input
+    // planes), lin = z . Wg^T on the matrix cores, then gate, pool, store
     float *yc = y + clip * static_cast<long>(H) * (W / 2) * COUT;
     const uint4 *gbp = gp + ncol * 2 + half;
-    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int MG = G::MG;
 #pragma unroll
     for (int m0 = 0; m0 < MT; m0 += MG) {
+        __syncthreads();                 // readers of the planes (main loop / previous phase) are done
+#pragma unroll
+        for (int mt = 0; mt < MG; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    _Float16 hi, lo;
+                    split_f16(acc[m0 + mt][nt][r], hi, lo);
+                    const int off = (32 * MG * wm + 32 * mt + acc_row(r, half)) * G::ZSB + (ncol + 32 * nt) * 2;
+                    *reinterpret_cast<_Float16 *>(plane_h + off) = hi;
+                    *reinterpret_cast<_Float16 *>(plane_l + off) = lo;
+                }
+        __syncthreads();
         f32x16 lin[MG][NT];
 #pragma unroll
         for (int mt = 0; mt < MG; ++mt)
@@ -195,13 +253,11 @@ __global__ __launch_bounds__(256) void conv_split_kernel(
         const char *zh[MG], *zl[MG];
 #pragma unroll
         for (int mt = 0; mt < MG; ++mt) {
-            const int off = (32 * MT * wm + 32 * (m0 + mt) + col32) * G::ZSB + 16 * half;
+            const int off = (32 * MG * wm + 32 * mt + col32) * G::ZSB + 16 * half;
             zh[mt] = plane_h + off;
             zl[mt] = plane_l + off;
         }
-#pragma unroll 2
-        for (int ks = 0; ks < COUT / 16; ++ks)
-            split_kstep<MG, NT, COUT>(lin, zh, zl, ks * 32, gbp + static_cast<long>(ks) * (COUT * 4));
+        split_gemm<MG, NT, COUT, COUT / 16>(lin, zh, zl, gbp, [](int i) { return i * 32; });
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const float gsc = g_s[ncol + 32 * nt], bias = gb[ncol + 32 * nt];

@@ -601,10 +601,10 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             if ((rc = launch_conv_split<16, 32, 64, 4, 2, 16>(m, 1, actA, actB, nc, Tp, s))) return rc;
             if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<64, 128, 16, 2, 4, 64>(m, 3, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 8, 2, 4, 64>(m, 4, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 4, 2, 4, 64>(m, 5, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 2, 2, 4, 32>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<64, 128, 16, 2, 4, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 8, 2, 4, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 4, 2, 4, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 2, 2, 4, 16>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
             continue;
         }
         if ((rc = launch_conv<16, 32, 64>(m, 1, actA, actB, nc, Tp, s))) return rc;
@@ -725,7 +725,7 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
         std::vector<float> gb(w->glu_b[i], w->glu_b[i] + co);
         {
             // split-f16 copies: k-step order [chunk][tap][k-step in chunk], channels 16 per k-step
-            static const int kChunk[SEDMI_CRNN_LAYERS] = {0, 16, 32, 64, 64, 64, 32};
+            static const int kChunk[SEDMI_CRNN_LAYERS] = {0, 16, 32, 32, 32, 32, 16};
             const int cch = kChunk[i], ks_per = cch / 16, nchunk = ci / cch;
             const float *src = w->conv_w[i];
             const int S = split_scale_exp(src, static_cast<size_t>(co) * ci * 9);
