@@ -476,6 +476,8 @@ struct sedmi_crnn {
     // split-f16 variants (blocks 1..6): packed hi/lo weights, scales with the power-of-two weight scale undone
     uint16_t *d_wps[SEDMI_CRNN_LAYERS] = {}, *d_gps[SEDMI_CRNN_LAYERS] = {};
     float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {};
+    uint16_t *d_wihs[2] = {};          // split-f16 GRU input-projection weights
+    float wih_oscale[2] = {1.f, 1.f};
     int precision = SEDMI_PRECISION_SPLIT_F16;
     float *d_wih[2] = {}, *d_bi[2] = {}, *d_whh[2] = {}, *d_bhn[2] = {};
     float *d_wd = nullptr, *d_bd = nullptr;
@@ -627,7 +629,24 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
     float *outs[2] = {rec0, rec1};
     for (int layer = 0; layer < 2; ++layer) {
         const int K = layer == 0 ? GRU_H : 2 * GRU_H;
-        {
+        if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
+            sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj_split<128>" : "gru_input_proj_split<256>", s,
+                                     2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
+            const dim3 grid(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6);
+            const size_t lds2 = 2 * 128 * (128 * 2 + 16);
+            const uint4 *wsp = reinterpret_cast<const uint4 *>(m->d_wihs[layer]);
+            if (layer == 0) {
+                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 128>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+                hipLaunchKernelGGL((linear_split_kernel<768, 128>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
+                                   m->wih_oscale[layer], gi, rows);
+            } else {
+                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 256>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+                hipLaunchKernelGGL((linear_split_kernel<768, 256>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
+                                   m->wih_oscale[layer], gi, rows);
+            }
+        } else {
             sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj<128>" : "gru_input_proj<256>", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
             hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6), dim3(256),
@@ -765,6 +784,15 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
             auto blk = pack_kn8(GRU_H, 3 * GRU_H, [&](int k, int n) { return src[static_cast<size_t>(n) * GRU_H + k]; });
             whh.insert(whh.end(), blk.begin(), blk.end());
         }
+        {
+            int S = 100;
+            for (int d = 0; d < 2; ++d) S = std::min(S, split_scale_exp(w->gru_w_ih[l][d], static_cast<size_t>(3) * GRU_H * K));
+            auto wihs = pack_split(K / 16, 6 * GRU_H, S, [&](int ks, int k16, int n) {
+                return w->gru_w_ih[l][n / (3 * GRU_H)][static_cast<size_t>(n % (3 * GRU_H)) * K + ks * 16 + k16];
+            });
+            m->wih_oscale[l] = std::ldexp(1.0f, -S);
+            if ((rc = sedmi::upload(&m->d_wihs[l], wihs))) return fail(rc);
+        }
         if ((rc = sedmi::upload(&m->d_wih[l], wih)) || (rc = sedmi::upload(&m->d_bi[l], bi)) ||
             (rc = sedmi::upload(&m->d_whh[l], whh)) || (rc = sedmi::upload(&m->d_bhn[l], bhn)))
             return fail(rc);
@@ -787,6 +815,7 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
         (void)hipFree(m->d_wps[i]); (void)hipFree(m->d_gps[i]); (void)hipFree(m->d_ss[i]); (void)hipFree(m->d_gs[i]);
     }
     for (int l = 0; l < 2; ++l) {
+        (void)hipFree(m->d_wihs[l]);
         (void)hipFree(m->d_wih[l]); (void)hipFree(m->d_bi[l]); (void)hipFree(m->d_whh[l]); (void)hipFree(m->d_bhn[l]);
     }
     (void)hipFree(m->d_wd); (void)hipFree(m->d_bd);
