@@ -136,7 +136,10 @@ struct MelGeom {
     static constexpr int NPAIR = R1 / 2 + 1;           // bins lane + 64*j <= NC/2
 };
 
-template <int R1, int WAVES, int FPB>
+// ROW0 / NROW: the first-stage rows n1 in [ROW0, ROW0 + NROW) are the only ones whose 64 complex
+// points can carry a non-zero window tap (win 640 centred in n_fft 2048: rows 5..10 of 16); the
+// others are compile-time zeros, are never loaded, and their butterflies fold away.
+template <int R1, int WAVES, int FPB, int ROW0, int NROW>
 __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
     using G = MelGeom<R1>;
     constexpr int NC = G::NC;
@@ -160,13 +163,16 @@ __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
         melmeta[3 * i + 2] = a.mel_ptr[i];
     }
 
-    float w0[R1], w1[R1];          // window taps of this lane's samples
+    float w0[NROW], w1[NROW];      // window taps of this lane's samples
     float t1r[R1], t1i[R1];        // stage-1 twiddles  W_NC^(lane * k1), k1 = bitrev(p)
 #pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int n = 64 * (ROW0 + i) + lane;
+        w0[i] = a.win[2 * n];
+        w1[i] = a.win[2 * n + 1];
+    }
+#pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
-        const int n = 64 * n1 + lane;
-        w0[n1] = a.win[2 * n];
-        w1[n1] = a.win[2 * n + 1];
         const int k1 = bitrev<R1>(n1);
         const float2 t = a.tw_nc[(lane * k1) & (NC - 1)];
         t1r[n1] = t.x;
@@ -190,29 +196,48 @@ __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
     }
     __syncthreads();
 
+    // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use
+    constexpr int UPT = FPB / WAVES;                   // frames per wave per tile
+    auto load_raw = [&](long tile, int u, float (&r0)[NROW], float (&r1)[NROW]) {
+        const long clip = tile / a.tiles_per_clip;
+        const int t = static_cast<int>(tile - clip * a.tiles_per_clip) * FPB + wave + WAVES * u;
+        const bool live = tile < a.total_tiles && t < a.T;
+        const float *yc = a.y + clip * a.n_samples;
+        const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+            const long s = s_base + 2 * (64 * (ROW0 + i) + lane);
+            r0[i] = (live && s >= 0 && s < a.n_samples) ? yc[s] : 0.f;
+            r1[i] = (live && s + 1 >= 0 && s + 1 < a.n_samples) ? yc[s + 1] : 0.f;
+        }
+    };
+    float raw0[NROW], raw1[NROW];
+    load_raw(blockIdx.x, 0, raw0, raw1);
+
     for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         const long clip = tile / a.tiles_per_clip;
         const int f0 = static_cast<int>(tile - clip * a.tiles_per_clip) * FPB;
-        const float *yc = a.y + clip * a.n_samples;
 
-        for (int fi = wave; fi < FPB; fi += WAVES) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            const int fi = wave + WAVES * u;
             const int t = f0 + fi;
-            if (t >= a.T) break;                       // wave-uniform
             // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
             float re[R1], im[R1];
-            const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) {
                 re[n1] = 0.f;
                 im[n1] = 0.f;
-                if (64 * n1 + 63 >= a.zlo && 64 * n1 < a.zhi) {   // wave-uniform
-                    const long s = s_base + 2 * (64 * n1 + lane);
-                    const float x0 = (s >= 0 && s < a.n_samples) ? yc[s] : 0.f;
-                    const float x1 = (s + 1 >= 0 && s + 1 < a.n_samples) ? yc[s + 1] : 0.f;
-                    re[n1] = x0 * w0[n1];
-                    im[n1] = x1 * w1[n1];
-                }
             }
+#pragma unroll
+            for (int i = 0; i < NROW; ++i) {
+                re[ROW0 + i] = raw0[i] * w0[i];
+                im[ROW0 + i] = raw1[i] * w1[i];
+            }
+            // request the next frame of this wave (next u, or the first frame of the next tile)
+            if (u + 1 < UPT) load_raw(tile, u + 1, raw0, raw1);
+            else load_raw(tile + gridDim.x, 0, raw0, raw1);
+            if (t >= a.T) continue;                    // wave-uniform: frame past the end of the clip
             dif<R1>(re, im);
 #pragma unroll
             for (int p = 0; p < R1; ++p) {             // twiddle, then transpose A: [k1][n2]
@@ -494,13 +519,13 @@ int sedmi_mel_filterbank(const sedmi_mel_plan *p, float *host_out) {
 
 }  // extern "C"
 
-template <int R1, int WAVES, int FPB>
+template <int R1, int WAVES, int FPB, int ROW0 = 0, int NROW = R1>
 static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
     a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, FPB));
     a.total_tiles = n_clips * a.tiles_per_clip;
     const size_t lds = mel_lds_bytes<R1, WAVES, FPB>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
-    auto kern = mel_kernel<R1, WAVES, FPB>;
+    auto kern = mel_kernel<R1, WAVES, FPB, ROW0, NROW>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const long grid = std::min<long>(a.total_tiles, 2L * p->num_cus);
@@ -534,7 +559,10 @@ int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->n_fft) {
         case 1024: return launch_mel<8, 8, 16>(p, a, n_clips, s);
-        case 2048: return launch_mel<16, 8, 16>(p, a, n_clips, s);
+        case 2048:
+            // window confined to first-stage rows 5..10 (e.g. win 640): specialised instance
+            if (p->zlo >= 5 * 64 && p->zhi <= 11 * 64) return launch_mel<16, 8, 16, 5, 6>(p, a, n_clips, s);
+            return launch_mel<16, 8, 16>(p, a, n_clips, s);
         default:   return launch_mel<32, 4, 8>(p, a, n_clips, s);
     }
 }
