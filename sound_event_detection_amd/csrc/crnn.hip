@@ -99,12 +99,33 @@ struct Conv0Params {
     float gb[16];
 };
 
-__global__ __launch_bounds__(256) void conv0_kernel(const float *__restrict__ x, const Conv0Params *__restrict__ prm,
+// Weights sit in LDS as float4 rows per output channel (every lane reads the same address: a
+// broadcast, no bank conflict): [co][0..2] = 9 taps (+3 pad), [co][3..6] = GLU row, [co][7] = (s, t, gb, 0).
+__global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__ x, const Conv0Params *__restrict__ prm,
                                                     float *__restrict__ y, long n_clips, int T, int F, int Tp) {
     // x [clip][T][F], y [clip][Tp][F/2][16]
+    __shared__ float4 wsm[16][8];
+    if (threadIdx.x < 128) {
+        const int co = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < 3) {
+            v.x = prm->w[co][4 * j];
+            if (4 * j + 1 < 9) { v.y = prm->w[co][4 * j + 1]; v.z = prm->w[co][4 * j + 2]; v.w = prm->w[co][4 * j + 3]; }
+        } else if (j < 7) {
+            v = make_float4(prm->g[co][4 * (j - 3)], prm->g[co][4 * (j - 3) + 1], prm->g[co][4 * (j - 3) + 2],
+                            prm->g[co][4 * (j - 3) + 3]);
+        } else {
+            v = make_float4(prm->s[co], prm->t[co], prm->gb[co], 0.f);
+        }
+        wsm[co][j] = v;
+    }
+    __syncthreads();
     const int Fp = F / 2;
     const long total = n_clips * Tp * Fp;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += 256L * gridDim.x) {
+    // one output position per thread, no grid-stride loop: with a loop the weight reads are
+    // loop-invariant and the compiler hoists all 448 of them into registers
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx < total) {
         const int w2 = static_cast<int>(idx % Fp);
         const long rest = idx / Fp;
         const int h2 = static_cast<int>(rest % Tp);
@@ -123,36 +144,38 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float *__restrict__ x,
         float z[4][16];
 #pragma unroll
         for (int co = 0; co < 16; ++co) {
+            const float4 wa = wsm[co][0], wb = wsm[co][1], wc4 = wsm[co][2], st = wsm[co][7];
+            const float wv[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc4.x};
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = prm->w[co][ky * 3 + kx];
+                for (int p = 0; p < 4; ++p) a[p] = fmaf(patch[(p >> 1) + k / 3][(p & 1) + k % 3], wv[k], a[p]);
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) a[p] = fmaf(patch[(p >> 1) + ky][(p & 1) + kx], wv, a[p]);
-                }
-            const float sc = prm->s[co], sh = prm->t[co];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) z[p][co] = fmaf(a[p], sc, sh);
+            for (int p = 0; p < 4; ++p) z[p][co] = fmaf(a[p], st.x, st.y);
+            // keep each channel's weight reads next to their use (otherwise all 128 float4 reads are
+            // clustered up front and spill)
+            __builtin_amdgcn_sched_barrier(0);
         }
         float o[16];
 #pragma unroll
         for (int co = 0; co < 16; ++co) {
-            float gl[4];
-            const float gb = prm->gb[co];
+            const float gb = wsm[co][7].z;
+            float gl[4] = {gb, gb, gb, gb};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) gl[p] = gb;
+            for (int j = 0; j < 4; ++j) {
+                const float4 g4 = wsm[co][3 + j];
+                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-            for (int ci = 0; ci < 16; ++ci) {
-                const float wv = prm->g[co][ci];
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) gl[p] = fmaf(z[p][ci], wv, gl[p]);
+                    for (int p = 0; p < 4; ++p) gl[p] = fmaf(z[p][4 * j + c], gv[c], gl[p]);
             }
             float sum = 0.f;
 #pragma unroll
             for (int p = 0; p < 4; ++p) sum += gl[p] * sigmoidf_fast(z[p][co]);
             o[co] = 0.25f * sum;
+            __builtin_amdgcn_sched_barrier(0);
         }
         float4 *dst = reinterpret_cast<float4 *>(y + idx * 16);
 #pragma unroll
@@ -591,7 +614,7 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         const long nc = std::min<long>(kCnnChunk, n_clips - c0);
         const float *x = feats + c0 * static_cast<long>(T) * 128;
         const long total0 = nc * Tp * 64;
-        const unsigned grid0 = static_cast<unsigned>(std::min<long>(sedmi::ceil_div(total0, 256), 1L << 20));
+        const unsigned grid0 = static_cast<unsigned>(sedmi::ceil_div(total0, 256));
         {
             const double pos = static_cast<double>(nc) * (2.0 * Tp) * 128;
             sedmi::ProfileScope prof("conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
