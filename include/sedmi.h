@@ -167,6 +167,62 @@ int sedmi_crnn_head_f32(const sedmi_crnn *model, const float *rec, int64_t n_row
                         float *probs, void *stream);
 
 /* ------------------------------------------------------------------------
+ * ShakeRCNN eval-mode forward — replaces ShakeRCNN.forward (models.py:124-142)
+ * with its three ShakeCNNBlocks (models.py:155-180) and ShakeShakeBlocks
+ * (models.py:70-100).
+ *
+ * Weight pointers are HOST float32 arrays in the layouts of the reference
+ * state_dict; index b = block (cnn1, cnn2, cnn3):
+ *   conv_w[b]  cnn{b+1}.conv.weight            [2*out, in, k, k]  (k = 5, 3, 3; in = 1, 16, 32; out = 16, 32, 64)
+ *   conv_b[b]  cnn{b+1}.conv.bias              [2*out]
+ *   bn1_*[b]   cnn{b+1}.bn1.{weight,bias,running_mean,running_var}   [2*out]   (eps 1e-5)
+ *   br1_w/br2_w[b]  cnn{b+1}.shake.branch{1,2}.weight  [out, out, 3, 3];  br1_b/br2_b: bias [out]
+ *   bn2_*[b]   cnn{b+1}.bn2.*                  [out]
+ *   gru_*[d]   rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l0{,_reverse}  [3072,6144] [3072,1024] [3072] [3072]
+ *   ln_w/ln_b  layernorm.{weight,bias}         [2048]
+ *   fc_w/fc_b  fc1.{weight,bias}               [n_class, 2048] [n_class]
+ * ------------------------------------------------------------------------ */
+typedef struct sedmi_shake_rcnn sedmi_shake_rcnn;
+
+typedef struct sedmi_shake_cnn_weights {
+    const float *conv_w[3], *conv_b[3];
+    const float *bn1_w[3], *bn1_b[3], *bn1_mean[3], *bn1_var[3];
+    const float *br1_w[3], *br1_b[3], *br2_w[3], *br2_b[3];
+    const float *bn2_w[3], *bn2_b[3], *bn2_mean[3], *bn2_var[3];
+} sedmi_shake_cnn_weights;
+
+typedef struct sedmi_shake_rcnn_weights {
+    int n_class;
+    sedmi_shake_cnn_weights cnn;
+    const float *gru_w_ih[2], *gru_w_hh[2], *gru_b_ih[2], *gru_b_hh[2];
+    const float *ln_w, *ln_b, *fc_w, *fc_b;
+} sedmi_shake_rcnn_weights;
+
+/* ShakeRCNN(num_classes) + load_state_dict (models.py:105-121): repacks the
+ * weights for the kernels and uploads them to the current device. */
+int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weights *w);
+int sedmi_shake_rcnn_destroy(sedmi_shake_rcnn *model);
+
+/* Device scratch needed for n_clips clips of T frames x 768 bins (0 on bad input). */
+size_t sedmi_shake_rcnn_workspace_bytes(const sedmi_shake_rcnn *model, int64_t n_clips, int64_t T);
+
+/* feats [n_clips, T, 768] (device) -> logits [n_clips, T/4, n_class] (device);
+ * T must be a multiple of 4.  alphas: three HOST floats, the ShakeShake mixing
+ * weights of cnn1..cnn3; the reference draws each with torch.rand(1) on every
+ * eval-mode forward (models.py:88-91), so the caller supplies them (draw them
+ * the same way to reproduce the reference's stream, or pass 0.5 for the
+ * expectation).  Dropout is the identity in eval mode. */
+int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *model, const float *feats, int64_t n_clips,
+                                 int64_t T, const float *alphas, float *logits,
+                                 void *ws, size_t ws_bytes, void *stream);
+
+/* Stage-level entry point for parity tests: the three ShakeCNNBlocks followed
+ * by transpose(1,2) + flatten (models.py:127-134): feats -> seq [n_clips, T/4, 6144]
+ * with the reference's (channel, frequency) order along the last axis. */
+int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *model, const float *feats, int64_t n_clips, int64_t T,
+                        const float *alphas, float *seq, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
  * Thresholding and event decoding.
  * ------------------------------------------------------------------------ */
 

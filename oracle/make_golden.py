@@ -8,6 +8,7 @@ What is executed from the reference:
   * evaluation.py  -> get_prediction_from_raw_output  (decode goldens)
   * nnet/CNN.py    -> CNN                              (conv-stack goldens)
   * nnet/RNN.py    -> BidirectionalGRU                 (recurrent goldens)
+  * models.py      -> ShakeRCNN, ShakeTransformer      (Shake-model goldens)
 Each file is loaded by path with importlib (no package import), so
 nnet/CRNN.py — which imports torchaudio, absent here — is never touched.
 The CRNN glue between the two modules and the strong head
@@ -148,6 +149,58 @@ def make_crnn(cnn_mod, rnn_mod):
     print("crnn small goldens:", tuple(p2.shape))
 
 
+def _load_models():
+    """models.py:5 builds torch.device("") on a host without a GPU, which raises; report a GPU for the
+    duration of the import only, then point the module's global at the CPU."""
+    real = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    try:
+        mod = _load("ref_models", "models.py")
+    finally:
+        torch.cuda.is_available = real
+    mod.device = torch.device("cpu")
+    return mod
+
+
+def _shake_alphas(seed):
+    """The three torch.rand(1) draws of an eval-mode forward (models.py:91) after manual_seed(seed)."""
+    torch.manual_seed(seed)
+    return np.array([float(torch.rand(1)) for _ in range(3)], dtype=np.float32)
+
+
+def make_shake(models):
+    sys.path.insert(0, ROOT)
+    from sound_event_detection_amd import synth
+
+    out = {}
+    for tag, cls, spec_fn in (("rcnn", models.ShakeRCNN, synth.shake_rcnn_state_dict_spec),
+                              ("transformer", models.ShakeTransformer, synth.shake_transformer_state_dict_spec)):
+        sd = synth.synth_shake_state_dict(spec_fn(10), 0)
+        model = cls(10, 0.0)
+        model.load_state_dict(sd)
+        model.eval()
+        # small case (inputs stored), with the intermediate [B, T/4, 6144] sequence of models.py:133-134
+        small = synth.synth_shake_feats(1, 2, 64)
+        # full-size case: one 10 s clip = 1000 x 768 (inputs regenerated from the seed by the tests)
+        full = synth.synth_shake_feats(2, 1, 1000)
+        with torch.no_grad():
+            for name, feats, seed in (("small", small, 11), ("full", full, 12)):
+                alphas = _shake_alphas(seed)
+                torch.manual_seed(seed)
+                logits = model(torch.from_numpy(feats))
+                out[f"{tag}_{name}_alphas"] = alphas
+                out[f"{tag}_{name}_logits"] = logits.numpy()
+            if tag == "rcnn":
+                torch.manual_seed(11)
+                x = torch.from_numpy(small).unsqueeze(1)
+                x = model.cnn3(model.cnn2(model.cnn1(x)))
+                out["cnn_small_seq"] = torch.flatten(torch.transpose(x, 1, 2), start_dim=2).numpy()
+        print(f"shake {tag} goldens: small", out[f"{tag}_small_logits"].shape, "full", out[f"{tag}_full_logits"].shape,
+              "alphas", out[f"{tag}_full_alphas"])
+    out["small_feats_seed"] = np.array([1, 2, 64]); out["full_feats_seed"] = np.array([2, 1, 1000])
+    np.savez_compressed(os.path.join(OUT, "shake_seed0.npz"), **out)
+
+
 def copy_result_tables():
     """Two of the reference's own result tables (data, not code): they pin the
     TSV layout of training.py:364-365 and the float64 onset arithmetic."""
@@ -165,6 +218,8 @@ def main():
     rnn_mod = _load("ref_rnn", "nnet/RNN.py")
     make_decode(ev)
     make_crnn(cnn_mod, rnn_mod)
+    if "--skip-shake" not in sys.argv:
+        make_shake(_load_models())
     copy_result_tables()
 
 

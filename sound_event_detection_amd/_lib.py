@@ -38,6 +38,21 @@ class CrnnWeights(C.Structure):
     ]
 
 
+_FP3 = C.POINTER(C.c_float) * 3
+
+
+class ShakeCnnWeights(C.Structure):
+    _fields_ = [(n, _FP3) for n in ("conv_w", "conv_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var", "br1_w", "br1_b",
+                                   "br2_w", "br2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var")]
+
+
+class ShakeRcnnWeights(C.Structure):
+    _FP = C.POINTER(C.c_float)
+    _fields_ = [("n_class", C.c_int), ("cnn", ShakeCnnWeights),
+                ("gru_w_ih", _FP * 2), ("gru_w_hh", _FP * 2), ("gru_b_ih", _FP * 2), ("gru_b_hh", _FP * 2),
+                ("ln_w", _FP), ("ln_b", _FP), ("fc_w", _FP), ("fc_b", _FP)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -64,6 +79,11 @@ SIGNATURES = {
     "sedmi_crnn_cnn_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
     "sedmi_crnn_gru_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
     "sedmi_crnn_head_f32": (_I, [_VP, _VP, _I64, _VP, _VP]),
+    "sedmi_shake_rcnn_create": (_I, [C.POINTER(_VP), C.POINTER(ShakeRcnnWeights)]),
+    "sedmi_shake_rcnn_destroy": (_I, [_VP]),
+    "sedmi_shake_rcnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
+    "sedmi_shake_rcnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
+    "sedmi_shake_cnn_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
     "sedmi_threshold_i64": (_I, [_VP, _I64, _F, _I, _VP, _VP]),
     "sedmi_decode_workspace_bytes": (_SZ, [_I64, _I]),
     "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,

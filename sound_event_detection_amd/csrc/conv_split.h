@@ -11,7 +11,7 @@
 // |w| in [64, 128) (undone exactly inside the BatchNorm scale), and activations
 // are used as they are (BatchNorm keeps them O(1..100); |x| >= 65504 saturates).
 //
-// Included by crnn.hip inside its anonymous namespace (uses f32x16, acc_row,
+// Include after mfma_common.h, inside the same anonymous namespace (uses f32x16, acc_row,
 // sigmoidf_fast from there).
 #pragma once
 
@@ -67,12 +67,12 @@ struct SplitB {
 };
 
 // b: packed weights of one k-step, [plane][N][16] f16 as uint4 (16 B) units, already offset to
-// this lane's (column, half) of n-tile 0.
-template <int NT, int N>
-__device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b) {
+// this lane's (column, half) of n-tile 0; n2 = 2 * N (uint4 units between the hi and lo planes).
+template <int NT>
+__device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int n2) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const uint4 h = b[nt * 64], l = b[N * 2 + nt * 64];
+        const uint4 h = b[nt * 64], l = b[n2 + nt * 64];
         f.h[nt] = __builtin_bit_cast(f16x8, h);
         f.l[nt] = __builtin_bit_cast(f16x8, l);
     }
@@ -102,22 +102,23 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
 // acc += A . B over NSTEPS consecutive k-steps.  The weights of step i+1 are requested from L2
 // before the MFMAs of step i issue (their latency is several hundred cycles); the LDS operands are
 // read at the head of their own step and covered by the second wave on the SIMD.
-// a_off(i) = LDS byte offset of step i relative to ah/al; B advances by N*4 uint4 per step.
-template <int MT, int NT, int N, int NSTEPS, typename AOff>
+// a_off(i) = LDS byte offset of step i relative to ah/al; N = columns of the packed weight matrix
+// (B advances by 4*N uint4 per k-step: 2 planes x N columns x 32 B).
+template <int MT, int NT, int NSTEPS, typename AOff>
 __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
-                                           const uint4 *b, AOff a_off) {
-    constexpr int BS = N * 4;       // uint4 per k-step: 2 planes x N columns x 32 B
+                                           const uint4 *b, int N, AOff a_off) {
+    const int BS = N * 4, n2 = N * 2;
     SplitB<NT> b0, b1;
-    split_load_b<NT, N>(b0, b);
+    split_load_b<NT>(b0, b, n2);
 #pragma unroll
     for (int i = 0; i < NSTEPS; i += 2) {
         // sched_barrier pins "request the next step's weights, then run this step": left alone, the
         // scheduler sinks every load to just above its first use and the wave stalls on each one
-        if (i + 1 < NSTEPS) split_load_b<NT, N>(b1, b + (i + 1) * BS);
+        if (i + 1 < NSTEPS) split_load_b<NT>(b1, b + (i + 1) * BS, n2);
         __builtin_amdgcn_sched_barrier(0);
         split_step<MT, NT>(acc, ah, al, a_off(i), b0);
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < NSTEPS) split_load_b<NT, N>(b0, b + (i + 2) * BS);
+        if (i + 2 < NSTEPS) split_load_b<NT>(b0, b + (i + 2) * BS, n2);
         __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < NSTEPS) split_step<MT, NT>(acc, ah, al, a_off(i + 1), b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -205,11 +206,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             }
         }
         __syncthreads();
-        split_gemm<MT, NT, COUT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4),
-                                            [](int i) {
-                                                const int tap = i / G::KS, ks = i % G::KS;
-                                                return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
-                                            });
+        split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT,
+                                       [](int i) {
+                                           const int tap = i / G::KS, ks = i % G::KS;
+                                           return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
+                                       });
     }
 
     // ---- BatchNorm affine; z stays in the accumulators and goes to LDS as hi/lo planes
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             zh[mt] = plane_h + off;
             zl[mt] = plane_l + off;
         }
-        split_gemm<MG, NT, COUT, COUT / 16>(lin, zh, zl, gbp, [](int i) { return i * 32; });
+        split_gemm<MG, NT, COUT / 16>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; });
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const float gsc = g_s[ncol + 32 * nt], bias = gb[ncol + 32 * nt];
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float *__res
             *reinterpret_cast<uint2 *>(plane_l + r * PSB + c * 2) = lo;
         }
         __syncthreads();
-        split_gemm<2, 2, N, KC / 16>(acc, ah, al, bp + static_cast<long>(k0 / 16) * (N * 4),
-                                     [](int i) { return i * 32; });
+        split_gemm<2, 2, KC / 16>(acc, ah, al, bp + static_cast<long>(k0 / 16) * (N * 4), N,
+                                  [](int i) { return i * 32; });
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {

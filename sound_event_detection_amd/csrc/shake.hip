@@ -1,0 +1,799 @@
+// ShakeRCNN eval-mode forward for gfx950 (MI355X).
+//
+// Stands in for ShakeRCNN.forward (models.py:124-142) and its blocks:
+//   ShakeCNNBlock  (models.py:155-180): Conv(k, in -> 2*out, 'same') -> BatchNorm(eps 1e-5) ->
+//                  GLU(dim=1) [a * sigmoid(b), channels halved] -> ShakeShakeBlock -> BatchNorm ->
+//                  ReLU -> AvgPool
+//   ShakeShakeBlock (models.py:70-100): x * sigmoid(a*conv3x3_1(x) + (1-a)*conv3x3_2(x)); in eval
+//                  mode the reference draws a = torch.rand(1) per block per forward, so `a` is an
+//                  argument here (three values per forward)
+//   GRU(6144, 1024, bidirectional) -> LayerNorm(2048) -> LeakyReLU(0.01) -> Linear(2048, n_cls)
+//
+// Layout: activations channels-last [clip][time][freq][chan] float32.  The reference flattens
+// [B, 64, T', 96] as (chan, freq) per time step; here the GRU input is (freq, chan) and the
+// columns of W_ih are permuted once at model creation instead of moving data.
+//
+// Kernels
+//   shake_conv1_kernel   block 1 conv (5x5, 1 -> 32) + BN + GLU: VALU, weights as LDS broadcasts.
+//   conv2d_split_kernel  every other conv (3x3): implicit GEMM on the f16 matrix cores with the
+//                        split-f16 arithmetic of conv_split.h, 8 x 32 position tiles with halo.
+//                        MODE_GLU : BN affine + GLU halving (the two halves of a channel pair sit in
+//                                   two accumulator tiles of the same lane).
+//                        MODE_GATE: both shake branches as one GEMM with N = 2*C, mixed by `a` in the
+//                                   epilogue, gate with the centre input, BN affine, ReLU, average
+//                                   pool over positions ordered so that a pooling window is a run
+//                                   of accumulator registers of one lane.
+//   gemm_split_kernel    C = A.B + bias for the GRU input projection (M = clips*T', N = K = 6144).
+//   gru_big_step_kernel  one recurrence step for H = 1024: W_hh (25 MB for both directions) cannot
+//                        live in registers or LDS, so every step streams it from L2 / Infinity
+//                        Cache; a workgroup owns 32 clips x 32 hidden units x 3 gates, its four
+//                        waves split K and reduce through LDS, gate math included.
+//   ln_head_kernel       LayerNorm + LeakyReLU + Linear, one wave per frame.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+namespace {
+
+#include "mfma_common.h"
+#include "conv_split.h"
+
+// ---------------------------------------------------------------------------
+// block 1: 5x5 conv, 1 -> 32 channels, BN affine, GLU halving -> u [B][H][W][16]
+// ---------------------------------------------------------------------------
+struct ShakeConv1Params {
+    float w[32][28];     // [co][25 taps + 3 pad]
+    float s[32], t[32];  // z = conv * s + t
+};
+
+__global__ __launch_bounds__(256, 2) void shake_conv1_kernel(const float *__restrict__ x,
+                                                             const ShakeConv1Params *__restrict__ prm,
+                                                             float *__restrict__ u, long n_clips, int H, int W) {
+    __shared__ float4 wsm[32][8];      // [co][0..6] taps, [co][7] = (s, t, 0, 0)
+    {
+        const int co = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float4 v;
+        if (j < 7) v = make_float4(prm->w[co][4 * j], prm->w[co][4 * j + 1], prm->w[co][4 * j + 2], prm->w[co][4 * j + 3]);
+        else v = make_float4(prm->s[co], prm->t[co], 0.f, 0.f);
+        wsm[co][j] = v;
+    }
+    __syncthreads();
+    const int Wh = W / 2;
+    const long total = n_clips * H * Wh;
+    const long idx = blockIdx.x * 256L + threadIdx.x;      // one thread = two adjacent positions
+    if (idx >= total) return;
+    const int xi = static_cast<int>(idx % Wh) * 2;
+    const long rest = idx / Wh;
+    const int yi = static_cast<int>(rest % H);
+    const long b = rest / H;
+    const float *xb = x + b * static_cast<long>(H) * W;
+    float patch[5][6];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int yy = yi - 2 + r;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int xx = xi - 2 + c;
+            patch[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[static_cast<long>(yy) * W + xx] : 0.f;
+        }
+    }
+    float o[2][16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float z[2][2];                    // [GLU half][position]
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int co = c + 16 * hf;
+            float wv[28];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float4 q = wsm[co][j];
+                wv[4 * j] = q.x; wv[4 * j + 1] = q.y; wv[4 * j + 2] = q.z; wv[4 * j + 3] = q.w;
+            }
+            const float4 st = wsm[co][7];
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) {
+                a0 = fmaf(patch[k / 5][k % 5], wv[k], a0);
+                a1 = fmaf(patch[k / 5][k % 5 + 1], wv[k], a1);
+            }
+            z[hf][0] = fmaf(a0, st.x, st.y);
+            z[hf][1] = fmaf(a1, st.x, st.y);
+            __builtin_amdgcn_sched_barrier(0);      // keep each channel's weight reads next to their use
+        }
+        o[0][c] = z[0][0] * sigmoidf_fast(z[1][0]);
+        o[1][c] = z[0][1] * sigmoidf_fast(z[1][1]);
+    }
+    float4 *dst = reinterpret_cast<float4 *>(u + ((b * H + yi) * static_cast<long>(W) + xi) * 16);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[p * 4 + v] = make_float4(o[p][4 * v], o[p][4 * v + 1], o[p][4 * v + 2], o[p][4 * v + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 conv as split-f16 implicit GEMM over 8 x 32 position tiles
+// ---------------------------------------------------------------------------
+constexpr int MODE_GLU = 0, MODE_GATE = 1;
+constexpr int C2_TR = 8, C2_TC = 32;
+
+template <int CIN, int N, int CCH>
+struct Conv2dGeom {
+    static constexpr int TW = C2_TC + 2;
+    static constexpr int PSB = CCH * 2 + 16;
+    static constexpr int PLANE = (C2_TR + 2) * TW * PSB;
+    static constexpr int LDS_BYTES = 2 * PLANE;
+    static constexpr int NCHUNK = CIN / CCH;
+    static constexpr int KS = CCH / 16;
+    static constexpr int NT = N / 32;
+    static_assert(CIN % CCH == 0 && CCH % 16 == 0 && N % 32 == 0 && LDS_BYTES <= 80 * 1024, "bad conv2d geometry");
+};
+
+// position p (0..255) of a tile -> (row, col) inside the tile; a pooling window is a run of
+// consecutive p, hence of consecutive accumulator registers of one lane
+template <int PH, int PW>
+__device__ __forceinline__ void tile_pos(int p, int &ty, int &tx) {
+    if (PH == 2 && PW == 2) {
+        const int blk = p >> 2;
+        ty = 2 * (blk / (C2_TC / 2)) + ((p >> 1) & 1);
+        tx = 2 * (blk % (C2_TC / 2)) + (p & 1);
+    } else {
+        ty = p / C2_TC;
+        tx = p % C2_TC;
+    }
+}
+
+template <int CIN, int N, int CCH, int MODE, int PH, int PW>
+__global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
+    const float *__restrict__ x,      // [clip][H][W][CIN]
+    const uint4 *__restrict__ wp,     // packed split weights [9*CIN/16][2][N][16], k-step order chunk/tap/k
+    const float *__restrict__ es, const float *__restrict__ et,     // z = acc * es + et per GEMM column
+    float alpha,                                                     // MODE_GATE: branch mix
+    const float *__restrict__ s2, const float *__restrict__ t2,     // MODE_GATE: second BatchNorm affine
+    float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2]
+    int H, int W, int tiles_x, int tiles_y) {
+    using G = Conv2dGeom<CIN, N, CCH>;
+    constexpr int NT = G::NT, MT = 2, CO = N / 2;
+    static_assert(MODE == MODE_GLU || CIN == CO, "the gate multiplies the conv input channel by channel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *plane_h = smem, *plane_l = smem + G::PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * C2_TC;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * C2_TR;
+    const long clip = bid / tiles_y;
+    const float *xc = x + clip * static_cast<long>(H) * W * CIN;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const char *ah[MT], *al[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int ty, tx;
+        tile_pos<PH, PW>(64 * wave + 32 * mt + col32, ty, tx);
+        const int off = (ty * G::TW + tx) * G::PSB + 16 * half;
+        ah[mt] = plane_h + off;
+        al[mt] = plane_l + off;
+    }
+    const uint4 *bp = wp + col32 * 2 + half;
+
+    constexpr int POS = (C2_TR + 2) * G::TW;
+    constexpr int STAGE_F4 = POS * (CCH / 4);
+    constexpr int NLD = (STAGE_F4 + 255) / 256;
+    for (int c = 0; c < G::NCHUNK; ++c) {
+        float4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
+            const int yy = ty0 - 1 + pos / G::TW, xx = tx0 - 1 + pos % G::TW;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < STAGE_F4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v[j] = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(yy) * W + xx) * CIN + c * CCH + ch);
+        }
+        if (c) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
+            uint2 hi, lo;
+            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
+            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+            if (i < STAGE_F4) {
+                *reinterpret_cast<uint2 *>(plane_h + pos * G::PSB + ch * 2) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + pos * G::PSB + ch * 2) = lo;
+            }
+        }
+        __syncthreads();
+        split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (N * 4), N, [](int i) {
+            const int tap = i / G::KS, ks = i % G::KS;
+            return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
+        });
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float sc = es[col32 + 32 * nt], sh = et[col32 + 32 * nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], sc, sh);
+    }
+    if constexpr (MODE == MODE_GLU) {
+        float *yc = y + clip * static_cast<long>(H) * W * CO;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ty, tx;
+                tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                const int yy = ty0 + ty, xx = tx0 + tx;
+                if (yy < H && xx < W) {
+#pragma unroll
+                    for (int nt = 0; nt < NT / 2; ++nt)
+                        yc[(static_cast<long>(yy) * W + xx) * CO + col32 + 32 * nt] =
+                            acc[mt][nt][r] * sigmoidf_fast(acc[mt][nt + NT / 2][r]);
+                }
+            }
+    } else {
+        constexpr int NTC = CO >= 32 ? CO / 32 : 1;        // channel tiles after mixing the branches
+        constexpr int WIN = PH * PW;
+        const int Ho = H / PH, Wo = W / PW;
+        float *yc = y + clip * static_cast<long>(Ho) * Wo * CO;
+        const bool lane_ok = CO >= 32 || col32 < CO;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int ch = col32 + 32 * nt;
+            const float b2s = lane_ok ? s2[ch] : 0.f, b2t = lane_ok ? t2[ch] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z1 = acc[mt][nt][r];
+                    float z2;
+                    if constexpr (CO >= 32) z2 = acc[mt][nt + NTC][r];
+                    else z2 = __shfl_xor(z1, 16);          // branch 2 of channel c lives in column c + 16
+                    const float gate = sigmoidf_fast(alpha * z1 + (1.0f - alpha) * z2);
+                    int ty, tx;
+                    tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                    const int yy = ty0 + ty, xx = tx0 + tx;
+                    float uc = 0.f;
+                    if (lane_ok && yy < H && xx < W) uc = xc[(static_cast<long>(yy) * W + xx) * CIN + ch];
+                    const float val = fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
+                    sum += val;
+                    if ((r % WIN) == WIN - 1) {
+                        const int yo = yy / PH, xo = xx / PW;
+                        if (lane_ok && yo < Ho && xo < Wo)
+                            yc[(static_cast<long>(yo) * Wo + xo) * CO + ch] = sum * (1.0f / WIN);
+                        sum = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C[M][N] = (A[M][K] . B) * oscale + bias, split-f16; B packed [K/16][2][N][16]; N, K % 128 == 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float *__restrict__ A, long lda,
+                                                           const uint4 *__restrict__ bpk, int N, int K,
+                                                           const float *__restrict__ bias, float oscale,
+                                                           float *__restrict__ C, long ldc, long M) {
+    constexpr int KC = 128, PSB = KC * 2 + 16, PLANE = 128 * PSB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *plane_h = smem, *plane_l = smem + PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = static_cast<long>(blockIdx.x) * 128;
+    const int ncol = blockIdx.y * 128 + wn * 64 + col32;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const char *ah[2], *al[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int off = (64 * wm + 32 * mt + col32) * PSB + 16 * half;
+        ah[mt] = plane_h + off;
+        al[mt] = plane_l + off;
+    }
+    const uint4 *bp = bpk + ncol * 2 + half;
+    constexpr int NLD = 128 * (KC / 4) / 256;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        float4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) v[j] = *reinterpret_cast<const float4 *>(A + (m0 + r) * lda + k0 + c);
+        }
+        if (k0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
+            uint2 hi, lo;
+            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
+            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(plane_h + r * PSB + c * 2) = hi;
+            *reinterpret_cast<uint2 *>(plane_l + r * PSB + c * 2) = lo;
+        }
+        __syncthreads();
+        split_gemm<2, 2, KC / 16>(acc, ah, al, bp + static_cast<long>(k0 / 16) * (N * 4), N, [](int i) { return i * 32; });
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = bias ? bias[ncol + 32 * nt] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
+                if (row < M) C[row * ldc + ncol + 32 * nt] = fmaf(acc[mt][nt][r], oscale, bv);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// one GRU step, H = 1024.  grid (32 unit groups, clip tiles of 32, 2 directions)
+// ---------------------------------------------------------------------------
+constexpr int GB_H = 1024;
+
+__global__ __launch_bounds__(256) void gru_big_step_kernel(
+    const float *__restrict__ gi,       // [clip][T][2][3][1024]: W_ih x + b_ih (+ b_hh for r, z)
+    const uint4 *__restrict__ whh,      // packed split [2][1024/16][2][3072][16], columns [unit group][gate][32]
+    float whh_oscale, const float *__restrict__ bhn,   // [2][1024]
+    const float *__restrict__ h_prev, float *__restrict__ h_next,   // [2][clips][1024]
+    float *__restrict__ out,            // [clip][T][2048]
+    long n_clips, int T, int step) {
+    constexpr int KW = GB_H / 4;                      // K slice per wave
+    constexpr int PSB = KW * 2 + 16, PLANE = 32 * PSB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int ug = blockIdx.x, dir = blockIdx.z;
+    const long b0 = static_cast<long>(blockIdx.y) * 32;
+    const int t = dir ? T - 1 - step : step;
+    char *plane_h = smem + wave * 2 * PLANE, *plane_l = plane_h + PLANE;
+    const float *hp = h_prev + (static_cast<long>(dir) * n_clips) * GB_H;
+
+    // each wave stages its own K slice of h for the 32 clips
+    constexpr int NLD = 32 * (KW / 4) / 64;
+    float4 v[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = lane + 64 * j, r = i / (KW / 4), c = (i - r * (KW / 4)) * 4;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + r < n_clips) v[j] = *reinterpret_cast<const float4 *>(hp + (b0 + r) * GB_H + wave * KW + c);
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = lane + 64 * j, r = i / (KW / 4), c = (i - r * (KW / 4)) * 4;
+        uint2 hi, lo;
+        split2_f16(v[j].x, v[j].y, hi.x, lo.x);
+        split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+        *reinterpret_cast<uint2 *>(plane_h + r * PSB + c * 2) = hi;
+        *reinterpret_cast<uint2 *>(plane_l + r * PSB + c * 2) = lo;
+    }
+    __syncthreads();
+
+    f32x16 acc[1][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][g][r] = 0.f;
+    const char *ah[1] = {plane_h + col32 * PSB + 16 * half}, *al[1] = {plane_l + col32 * PSB + 16 * half};
+    const uint4 *bp = whh + (static_cast<long>(dir) * (GB_H / 16) + wave * (KW / 16)) * (3 * GB_H * 4) +
+                      (ug * 96 + col32) * 2 + half;
+    split_gemm<1, 3, KW / 16>(acc, ah, al, bp, 3 * GB_H, [](int i) { return i * 32; });
+
+    // reduce the four K slices through LDS, then the gate math: thread -> (clip row, unit)
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);     // [wave][gate][row][unit] = 4*3*32*32 floats = 48 KB
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + g) * 32 + acc_row(r, half)) * 32 + col32] = acc[0][g][r];
+    __syncthreads();
+    const float *hprow = hp;
+    float *hn = h_next + (static_cast<long>(dir) * n_clips) * GB_H;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int row = e >> 5, jj = e & 31;
+        const long b = b0 + row;
+        if (b >= n_clips) continue;
+        const int j = ug * 32 + jj;
+        float gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * 3 + g) * 32 + row) * 32 + jj];
+            gh[g] = s * whh_oscale;
+        }
+        const float *gp = gi + ((b * T + t) * 2 + dir) * (3L * GB_H) + j;
+        const float rg = sigmoidf_fast(gp[0] + gh[0]);
+        const float zg = sigmoidf_fast(gp[GB_H] + gh[1]);
+        const float ng = tanhf_fast(fmaf(rg, gh[2] + bhn[dir * GB_H + j], gp[2 * GB_H]));
+        const float hprev = hprow[b * GB_H + j];
+        const float hv = fmaf(zg, hprev - ng, ng);
+        hn[b * GB_H + j] = hv;
+        out[(b * T + t) * (2L * GB_H) + dir * GB_H + j] = hv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm(2048) -> LeakyReLU(0.01) -> Linear(2048, n_cls): one wave per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_head_kernel(const float *__restrict__ x, const float *__restrict__ lw,
+                                                      const float *__restrict__ lb, const float *__restrict__ fw,
+                                                      const float *__restrict__ fb, float *__restrict__ out,
+                                                      long n_rows, int n_cls) {
+    constexpr int D = 2 * GB_H, PER = D / 64;
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float *xr = x + row * D;
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float d = v[i] - mean;
+        q = fmaf(d, d, q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float n = (v[i] - mean) * rstd * lw[lane + 64 * i] + lb[lane + 64 * i];
+        v[i] = n > 0.f ? n : 0.01f * n;
+    }
+    for (int c = 0; c < n_cls; ++c) {
+        const float *wr = fw + static_cast<long>(c) * D;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) a = fmaf(v[i], wr[lane + 64 * i], a);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) out[row * n_cls + c] = a + fb[c];
+    }
+}
+
+// [clip][T'][96][64] (freq, chan) -> [clip][T'][64*96] in the reference's (chan, freq) order
+__global__ __launch_bounds__(256) void to_reference_order_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                 long n_rows) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n_rows * 6144) return;
+    const long row = i / 6144;
+    const int e = static_cast<int>(i - row * 6144), c = e / 96, f = e - c * 96;
+    dst[i] = src[row * 6144 + f * 64 + c];
+}
+
+constexpr int kShakeChunk = 16;     // clips per pass through the conv blocks (u1 is 49 MB per clip)
+
+struct BlockDev {
+    uint16_t *wa = nullptr, *wb = nullptr;      // packed split weights: conv A (blocks 2, 3), branches (all)
+    float *es_a = nullptr, *et_a = nullptr;     // conv A epilogue affine per GEMM column
+    float *es_b = nullptr, *et_b = nullptr;     // branch conv epilogue (scale undo, bias) per GEMM column
+    float *s2 = nullptr, *t2 = nullptr;         // second BatchNorm affine
+};
+
+}  // namespace
+
+struct sedmi_shake_rcnn {
+    int n_class = 0;
+    ShakeConv1Params *d_c1 = nullptr;
+    BlockDev blk[3];
+    uint16_t *d_wih = nullptr, *d_whh = nullptr;
+    float wih_oscale = 1.f, whh_oscale = 1.f;
+    float *d_bi = nullptr, *d_bhn = nullptr, *d_lw = nullptr, *d_lb = nullptr, *d_fw = nullptr, *d_fb = nullptr;
+};
+
+namespace {
+
+struct ShakeScratch {
+    float *u1, *y1, *u2, *y2, *u3, *seq, *gi, *rec, *h0, *h1;
+    size_t bytes;
+};
+
+ShakeScratch carve_shake(void *ws, long n, long T) {
+    ShakeScratch sc{};
+    size_t off = 0;
+    auto take = [&](size_t n_floats) {
+        float *p = reinterpret_cast<float *>(static_cast<char *>(ws) + off);
+        off += sedmi::align_up(n_floats * sizeof(float), 256);
+        return p;
+    };
+    const long ch = std::min<long>(n, kShakeChunk), T2 = T / 2, T4 = T / 4;
+    sc.u1 = take(static_cast<size_t>(ch) * T * 768 * 16);
+    sc.y1 = take(static_cast<size_t>(ch) * T2 * 384 * 16);
+    sc.u2 = take(static_cast<size_t>(ch) * T2 * 384 * 32);
+    sc.y2 = take(static_cast<size_t>(ch) * T4 * 192 * 32);
+    sc.u3 = take(static_cast<size_t>(ch) * T4 * 192 * 64);
+    sc.seq = take(static_cast<size_t>(n) * T4 * 6144);
+    sc.gi = take(static_cast<size_t>(n) * T4 * 6144);
+    sc.rec = take(static_cast<size_t>(n) * T4 * 2048);
+    sc.h0 = take(static_cast<size_t>(2) * n * GB_H);
+    sc.h1 = take(static_cast<size_t>(2) * n * GB_H);
+    sc.bytes = off;
+    return sc;
+}
+
+template <int CIN, int N, int CCH, int MODE, int PH, int PW>
+int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const float *et, float alpha, const float *s2,
+                  const float *t2, const float *x, float *y, long n, int H, int W, hipStream_t s) {
+    using G = Conv2dGeom<CIN, N, CCH>;
+    const int tiles_x = static_cast<int>(sedmi::ceil_div(W, C2_TC)), tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
+    auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW>;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    const double pos = static_cast<double>(n) * H * W;
+    sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
+                             pos * 4.0 * (CIN + (MODE == MODE_GLU ? N / 2.0 : CIN + N / 2.0 / (PH * PW))));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n * tiles_x * tiles_y)), dim3(256), G::LDS_BYTES, s, x,
+                       reinterpret_cast<const uint4 *>(wp), es, et, alpha, s2, t2, y, H, W, tiles_x, tiles_y);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int run_shake_cnn(const sedmi_shake_rcnn *m, const float *feats, long n, int T, const float *alphas, float *seq,
+                  const ShakeScratch &sc, hipStream_t s) {
+    const int T2 = T / 2, T4 = T / 4;
+    for (long c0 = 0; c0 < n; c0 += kShakeChunk) {
+        const long nc = std::min<long>(kShakeChunk, n - c0);
+        const float *x = feats + c0 * static_cast<long>(T) * 768;
+        {
+            const long total = nc * T * 384;
+            sedmi::ProfileScope prof("shake_conv1", s, 2.0 * 25 * 32 * nc * T * 768.0, 4.0 * nc * T * 768.0 * 17);
+            hipLaunchKernelGGL(shake_conv1_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(total, 256))), dim3(256), 0,
+                               s, x, m->d_c1, sc.u1, nc, T, 768);
+            SEDMI_CHECK_LAUNCH();
+        }
+        int rc;
+        const BlockDev *b = m->blk;
+        if ((rc = launch_conv2d<16, 32, 16, MODE_GATE, 2, 2>("shake_gate<16>", b[0].wb, b[0].es_b, b[0].et_b, alphas[0],
+                                                            b[0].s2, b[0].t2, sc.u1, sc.y1, nc, T, 768, s))) return rc;
+        if ((rc = launch_conv2d<16, 64, 16, MODE_GLU, 1, 1>("shake_conv<16,64>", b[1].wa, b[1].es_a, b[1].et_a, 0.f,
+                                                           nullptr, nullptr, sc.y1, sc.u2, nc, T2, 384, s))) return rc;
+        if ((rc = launch_conv2d<32, 64, 32, MODE_GATE, 2, 2>("shake_gate<32>", b[1].wb, b[1].es_b, b[1].et_b, alphas[1],
+                                                            b[1].s2, b[1].t2, sc.u2, sc.y2, nc, T2, 384, s))) return rc;
+        if ((rc = launch_conv2d<32, 128, 32, MODE_GLU, 1, 1>("shake_conv<32,128>", b[2].wa, b[2].es_a, b[2].et_a, 0.f,
+                                                            nullptr, nullptr, sc.y2, sc.u3, nc, T4, 192, s))) return rc;
+        if ((rc = launch_conv2d<64, 128, 32, MODE_GATE, 1, 2>("shake_gate<64>", b[2].wb, b[2].es_b, b[2].et_b, alphas[2],
+                                                             b[2].s2, b[2].t2, sc.u3, seq + c0 * T4 * 6144, nc, T4, 192,
+                                                             s))) return rc;
+    }
+    return SEDMI_OK;
+}
+
+int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
+    const long rows = n * T4;
+    {
+        const size_t lds = 2 * 128 * (128 * 2 + 16);
+        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        sedmi::ProfileScope prof("shake_gru_input_proj", s, 2.0 * rows * 6144.0 * 6144.0, 4.0 * rows * 2 * 6144.0);
+        hipLaunchKernelGGL(gemm_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6144 / 128), dim3(256),
+                           lds, s, seq, 6144L, reinterpret_cast<const uint4 *>(m->d_wih), 6144, 6144, m->d_bi,
+                           m->wih_oscale, sc.gi, 6144L, rows);
+        SEDMI_CHECK_LAUNCH();
+    }
+    SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));
+    const size_t lds = 4 * 2 * 32 * ((GB_H / 4) * 2 + 16);
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_big_step_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    float *hp = sc.h0, *hn = sc.h1;
+    sedmi::ProfileScope prof("shake_gru_steps", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
+    for (int step = 0; step < T4; ++step) {
+        hipLaunchKernelGGL(gru_big_step_kernel, dim3(GB_H / 32, static_cast<unsigned>(sedmi::ceil_div(n, 32)), 2), dim3(256),
+                           lds, s, sc.gi, reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, hp, hn,
+                           sc.rec, n, T4, step);
+        std::swap(hp, hn);
+    }
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weights *w) {
+    SEDMI_REQUIRE(out && w, "null argument");
+    *out = nullptr;
+    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
+    const sedmi_shake_cnn_weights &c = w->cnn;
+    for (int i = 0; i < 3; ++i)
+        SEDMI_REQUIRE(c.conv_w[i] && c.conv_b[i] && c.bn1_w[i] && c.bn1_b[i] && c.bn1_mean[i] && c.bn1_var[i] &&
+                          c.br1_w[i] && c.br1_b[i] && c.br2_w[i] && c.br2_b[i] && c.bn2_w[i] && c.bn2_b[i] &&
+                          c.bn2_mean[i] && c.bn2_var[i], "null weight pointer in block %d", i + 1);
+    for (int d = 0; d < 2; ++d)
+        SEDMI_REQUIRE(w->gru_w_ih[d] && w->gru_w_hh[d] && w->gru_b_ih[d] && w->gru_b_hh[d], "null GRU weight pointer");
+    SEDMI_REQUIRE(w->ln_w && w->ln_b && w->fc_w && w->fc_b, "null head weight pointer");
+
+    auto *m = new sedmi_shake_rcnn();
+    m->n_class = w->n_class;
+    int rc = SEDMI_OK;
+    auto fail = [&](int code) { sedmi_shake_rcnn_destroy(m); return code; };
+    static const int cin[3] = {1, 16, 32}, cout[3] = {16, 32, 64};
+    const float eps = 1e-5f;
+    for (int i = 0; i < 3; ++i) {
+        const int ci = cin[i], co = cout[i], n2 = 2 * co;
+        std::vector<float> s1(n2), t1(n2), s2(co), t2(co);
+        for (int k = 0; k < n2; ++k) {
+            s1[k] = c.bn1_w[i][k] / std::sqrt(c.bn1_var[i][k] + eps);
+            t1[k] = (c.conv_b[i][k] - c.bn1_mean[i][k]) * s1[k] + c.bn1_b[i][k];
+        }
+        for (int k = 0; k < co; ++k) {
+            s2[k] = c.bn2_w[i][k] / std::sqrt(c.bn2_var[i][k] + eps);
+            t2[k] = c.bn2_b[i][k] - c.bn2_mean[i][k] * s2[k];
+        }
+        BlockDev &b = m->blk[i];
+        if (i == 0) {
+            ShakeConv1Params p{};
+            for (int k = 0; k < 32; ++k) {
+                for (int tap = 0; tap < 25; ++tap) p.w[k][tap] = c.conv_w[0][k * 25 + tap];
+                p.s[k] = s1[k];
+                p.t[k] = t1[k];
+            }
+            if (hipMalloc(reinterpret_cast<void **>(&m->d_c1), sizeof(p)) != hipSuccess ||
+                hipMemcpy(m->d_c1, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(sedmi::set_error(SEDMI_EHIP, "uploading block 1 parameters failed"));
+        } else {
+            const int cch = ci >= 32 ? 32 : 16, ksp = cch / 16;
+            const float *src = c.conv_w[i];
+            const int S = split_scale_exp(src, static_cast<size_t>(n2) * ci * 9);
+            auto wa = pack_split(9 * ci / 16, n2, S, [&](int kidx, int k16, int n) {
+                const int ks = kidx % ksp, tap = (kidx / ksp) % 9, ch = (kidx / (ksp * 9)) * cch + ks * 16 + k16;
+                return src[(static_cast<size_t>(n) * ci + ch) * 9 + tap];
+            });
+            std::vector<float> es(n2);
+            for (int k = 0; k < n2; ++k) es[k] = std::ldexp(s1[k], -S);
+            if ((rc = sedmi::upload(&b.wa, wa)) || (rc = sedmi::upload(&b.es_a, es)) || (rc = sedmi::upload(&b.et_a, t1)))
+                return fail(rc);
+        }
+        {   // both shake branches as one GEMM: columns [branch 1 | branch 2]
+            const int cch = co >= 32 ? 32 : 16, ksp = cch / 16;
+            const float *w1 = c.br1_w[i], *w2 = c.br2_w[i];
+            const int S = std::min(split_scale_exp(w1, static_cast<size_t>(co) * co * 9),
+                                   split_scale_exp(w2, static_cast<size_t>(co) * co * 9));
+            auto wb = pack_split(9 * co / 16, n2, S, [&](int kidx, int k16, int n) {
+                const int ks = kidx % ksp, tap = (kidx / ksp) % 9, ch = (kidx / (ksp * 9)) * cch + ks * 16 + k16;
+                const float *src = n < co ? w1 : w2;
+                return src[(static_cast<size_t>(n % co) * co + ch) * 9 + tap];
+            });
+            std::vector<float> es(n2, std::ldexp(1.0f, -S)), et(n2);
+            for (int k = 0; k < co; ++k) {
+                et[k] = c.br1_b[i][k];
+                et[co + k] = c.br2_b[i][k];
+            }
+            if ((rc = sedmi::upload(&b.wb, wb)) || (rc = sedmi::upload(&b.es_b, es)) || (rc = sedmi::upload(&b.et_b, et)) ||
+                (rc = sedmi::upload(&b.s2, s2)) || (rc = sedmi::upload(&b.t2, t2)))
+                return fail(rc);
+        }
+    }
+    {   // GRU input projection: GEMM K index is (freq, chan); the reference's is chan * 96 + freq
+        int S = 100;
+        for (int d = 0; d < 2; ++d) S = std::min(S, split_scale_exp(w->gru_w_ih[d], static_cast<size_t>(3072) * 6144));
+        auto wih = pack_split(6144 / 16, 6144, S, [&](int ks, int k16, int n) {
+            const int k = ks * 16 + k16, f = k / 64, ch = k % 64;
+            return w->gru_w_ih[n / 3072][static_cast<size_t>(n % 3072) * 6144 + ch * 96 + f];
+        });
+        m->wih_oscale = std::ldexp(1.0f, -S);
+        std::vector<float> bi(6144), bhn(2 * GB_H);
+        for (int d = 0; d < 2; ++d) {
+            for (int n = 0; n < 3072; ++n) bi[d * 3072 + n] = w->gru_b_ih[d][n] + (n < 2 * GB_H ? w->gru_b_hh[d][n] : 0.f);
+            for (int n = 0; n < GB_H; ++n) bhn[d * GB_H + n] = w->gru_b_hh[d][2 * GB_H + n];
+        }
+        int Sh = 100;
+        for (int d = 0; d < 2; ++d) Sh = std::min(Sh, split_scale_exp(w->gru_w_hh[d], static_cast<size_t>(3072) * GB_H));
+        std::vector<uint16_t> whh;
+        for (int d = 0; d < 2; ++d) {
+            const float *src = w->gru_w_hh[d];
+            auto blk = pack_split(GB_H / 16, 3 * GB_H, Sh, [&](int ks, int k16, int n) {
+                const int ug = n / 96, g = (n % 96) / 32, jj = n % 32;      // columns [unit group][gate][32]
+                return src[static_cast<size_t>(g * GB_H + ug * 32 + jj) * GB_H + ks * 16 + k16];
+            });
+            whh.insert(whh.end(), blk.begin(), blk.end());
+        }
+        m->whh_oscale = std::ldexp(1.0f, -Sh);
+        std::vector<float> lw(w->ln_w, w->ln_w + 2048), lb(w->ln_b, w->ln_b + 2048);
+        std::vector<float> fw(w->fc_w, w->fc_w + static_cast<size_t>(w->n_class) * 2048), fb(w->fc_b, w->fc_b + w->n_class);
+        if ((rc = sedmi::upload(&m->d_wih, wih)) || (rc = sedmi::upload(&m->d_whh, whh)) ||
+            (rc = sedmi::upload(&m->d_bi, bi)) || (rc = sedmi::upload(&m->d_bhn, bhn)) ||
+            (rc = sedmi::upload(&m->d_lw, lw)) || (rc = sedmi::upload(&m->d_lb, lb)) ||
+            (rc = sedmi::upload(&m->d_fw, fw)) || (rc = sedmi::upload(&m->d_fb, fb)))
+            return fail(rc);
+    }
+    *out = m;
+    return SEDMI_OK;
+}
+
+int sedmi_shake_rcnn_destroy(sedmi_shake_rcnn *m) {
+    if (!m) return SEDMI_OK;
+    (void)hipFree(m->d_c1);
+    for (auto &b : m->blk) {
+        (void)hipFree(b.wa); (void)hipFree(b.wb); (void)hipFree(b.es_a); (void)hipFree(b.et_a);
+        (void)hipFree(b.es_b); (void)hipFree(b.et_b); (void)hipFree(b.s2); (void)hipFree(b.t2);
+    }
+    (void)hipFree(m->d_wih); (void)hipFree(m->d_whh); (void)hipFree(m->d_bi); (void)hipFree(m->d_bhn);
+    (void)hipFree(m->d_lw); (void)hipFree(m->d_lb); (void)hipFree(m->d_fw); (void)hipFree(m->d_fb);
+    delete m;
+    return SEDMI_OK;
+}
+
+size_t sedmi_shake_rcnn_workspace_bytes(const sedmi_shake_rcnn *m, int64_t n_clips, int64_t T) {
+    if (!m || n_clips <= 0 || T < 4) return 0;
+    return carve_shake(nullptr, n_clips, T).bytes;
+}
+
+static int shake_check(const sedmi_shake_rcnn *m, int64_t n, int64_t T) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(n >= 0 && T >= 0 && T < (1 << 24) && n < (1LL << 31), "bad shape");
+    SEDMI_REQUIRE(T % 4 == 0, "T = %lld: the three pooling stages need a multiple of 4 frames", static_cast<long long>(T));
+    return SEDMI_OK;
+}
+
+int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *m, const float *feats, int64_t n, int64_t T, const float *alphas,
+                        float *seq_ref_order, void *ws, size_t ws_bytes, void *stream) {
+    int rc = shake_check(m, n, T);
+    if (rc) return rc;
+    if (n == 0 || T == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && alphas && seq_ref_order && ws, "null pointer");
+    ShakeScratch sc = carve_shake(ws, n, T);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = run_shake_cnn(m, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
+    const long rows = n * (T / 4);
+    hipLaunchKernelGGL(to_reference_order_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows * 6144, 256))), dim3(256), 0,
+                       s, sc.seq, seq_ref_order, rows);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *m, const float *feats, int64_t n, int64_t T,
+                                 const float *alphas, float *logits, void *ws, size_t ws_bytes, void *stream) {
+    int rc = shake_check(m, n, T);
+    if (rc) return rc;
+    if (n == 0 || T == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
+    ShakeScratch sc = carve_shake(ws, n, T);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T4 = static_cast<int>(T / 4);
+    if ((rc = run_shake_cnn(m, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
+    if ((rc = run_shake_gru(m, sc.seq, n, T4, sc, s))) return rc;
+    const long rows = n * T4;
+    sedmi::ProfileScope prof("shake_ln_head", s, 2.0 * rows * 2048.0 * m->n_class, 4.0 * rows * (2048.0 + m->n_class));
+    hipLaunchKernelGGL(ln_head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s, sc.rec,
+                       m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+"""ShakeRCNN on MI355X behind the reference's interface.
+
+Mirrors /root/reference/models.py: ``ShakeRCNN(num_classes, dropout=0)``
+(:105-121), ``forward(x) -> logits [B, T/4, num_classes]`` (:124-142),
+``get_weak_logits`` (:144-152) and the state_dict keys
+(``cnn{1,2,3}.{conv,bn1,shake.branch1,shake.branch2,bn2}.*``, ``rnn.*_l0[_reverse]``,
+``layernorm.*``, ``fc1.*``), so ``load_state_dict`` of a reference checkpoint works.
+
+The module tree only owns tensors; ``forward`` packs them once into a
+``sedmi_shake_rcnn`` handle and runs the HIP kernels of csrc/shake.hip through
+the C ABI.  Inference only, CUDA (ROCm) tensors only, no CPU path.
+
+ShakeShake mixing weight: in eval mode the reference draws ``a = torch.rand(1)``
+per block on every forward (:88-91).  ``forward`` does the same (CPU generator,
+three draws in block order, so the same ``torch.manual_seed`` gives the same
+``a`` as the reference) unless ``alphas=(a1, a2, a3)`` is passed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class ShakeShakeBlock(nn.Module):
+    """Parameter container of models.py:70-100 (in == out, stride 1: identity shortcut)."""
+
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        if stride != 1 or in_channels != out_channels:
+            raise NotImplementedError("only the identity-shortcut ShakeShakeBlock the reference's models build")
+        self.branch1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1)
+        self.branch2 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1)
+
+
+class ShakeCNNBlock(nn.Module):
+    """Parameter container of models.py:155-180."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, avgpool_kernel=(1, 2),
+                 avgpool_stride=1, dropout=0):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, 2 * out_channels, kernel_size=kernel_size, padding="same", stride=stride)
+        self.bn1 = nn.BatchNorm2d(2 * out_channels)
+        self.shake = ShakeShakeBlock(out_channels, out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+
+
+class _ShakeBase(nn.Module):
+    N_BINS = 768
+
+    def _build_cnn(self, dropout):
+        self.cnn1 = ShakeCNNBlock(1, 16, dropout=dropout, kernel_size=(5, 5), avgpool_kernel=(2, 2), avgpool_stride=2)
+        self.cnn2 = ShakeCNNBlock(16, 32, dropout=dropout, avgpool_kernel=(2, 2), avgpool_stride=2)
+        self.cnn3 = ShakeCNNBlock(32, 64, dropout=dropout, avgpool_kernel=(1, 2), avgpool_stride=(1, 2))
+        self._handle = self._handle_sig = self._handle_fin = None
+
+    def _signature(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _release(self):
+        if self._handle_fin is not None:
+            self._handle_fin()
+        self._handle = self._handle_sig = self._handle_fin = None
+
+    def _host_state(self):
+        return {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()
+                if v.is_floating_point()}
+
+    @staticmethod
+    def _fill_cnn(w, p):
+        for i in range(3):
+            b = f"cnn{i + 1}."
+            w.conv_w[i], w.conv_b[i] = p(b + "conv.weight"), p(b + "conv.bias")
+            w.bn1_w[i], w.bn1_b[i] = p(b + "bn1.weight"), p(b + "bn1.bias")
+            w.bn1_mean[i], w.bn1_var[i] = p(b + "bn1.running_mean"), p(b + "bn1.running_var")
+            w.br1_w[i], w.br1_b[i] = p(b + "shake.branch1.weight"), p(b + "shake.branch1.bias")
+            w.br2_w[i], w.br2_b[i] = p(b + "shake.branch2.weight"), p(b + "shake.branch2.bias")
+            w.bn2_w[i], w.bn2_b[i] = p(b + "bn2.weight"), p(b + "bn2.bias")
+            w.bn2_mean[i], w.bn2_var[i] = p(b + "bn2.running_mean"), p(b + "bn2.running_var")
+
+    def _prepare(self, x, alphas):
+        if self.training:
+            raise RuntimeError("inference-only model: call model.eval() first")
+        if not x.is_cuda:
+            raise _lib.SedmiError("forward needs a CUDA (ROCm) tensor: the model runs in HIP kernels only")
+        if x.dim() != 3 or x.shape[2] != self.N_BINS:
+            raise ValueError(f"expected features [batch, frames, {self.N_BINS}], got {tuple(x.shape)}")
+        if x.shape[1] % 4:
+            raise ValueError(f"{x.shape[1]} frames: the HIP path needs a multiple of 4 (pooling (2,2),(2,2),(1,2))")
+        if alphas is None:
+            alphas = [float(torch.rand(1)) for _ in range(3)]       # models.py:91, block order
+        alphas = [float(a) for a in alphas]
+        if len(alphas) != 3:
+            raise ValueError("alphas: one ShakeShake mixing weight per block (3)")
+        return x.to(torch.float32).contiguous(), (C.c_float * 3)(*alphas)
+
+
+class ShakeRCNN(_ShakeBase):
+    def __init__(self, num_classes, dropout=0):
+        super().__init__()
+        self.num_classes = int(num_classes)
+        self.dropout = nn.Dropout(dropout)
+        self._build_cnn(dropout)
+        self.flatten = nn.Flatten(start_dim=2)
+        self.rnn = nn.GRU(6144, 1024, batch_first=True, bidirectional=True)
+        self.layernorm = nn.LayerNorm(2048)
+        self.fc1 = nn.Linear(2048, num_classes)
+        self.sigmoid = nn.Sigmoid()
+        self.softmax = nn.Softmax(dim=-1)
+        self.relu = nn.LeakyReLU()
+
+    def _get_handle(self, device):
+        sig = (device.index, self._signature())
+        if self._handle is not None and self._handle_sig == sig:
+            return self._handle
+        self._release()
+        sd = self._host_state()
+        fp = C.POINTER(C.c_float)
+
+        def p(key):
+            return C.cast(C.c_void_p(sd[key].data_ptr()), fp)
+
+        w = _lib.ShakeRcnnWeights()
+        w.n_class = self.num_classes
+        self._fill_cnn(w.cnn, p)
+        for d, sfx in enumerate(("", "_reverse")):
+            w.gru_w_ih[d], w.gru_w_hh[d] = p(f"rnn.weight_ih_l0{sfx}"), p(f"rnn.weight_hh_l0{sfx}")
+            w.gru_b_ih[d], w.gru_b_hh[d] = p(f"rnn.bias_ih_l0{sfx}"), p(f"rnn.bias_hh_l0{sfx}")
+        w.ln_w, w.ln_b = p("layernorm.weight"), p("layernorm.bias")
+        w.fc_w, w.fc_b = p("fc1.weight"), p("fc1.bias")
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().sedmi_shake_rcnn_create(C.byref(handle), C.byref(w)), "sedmi_shake_rcnn_create")
+        self._handle, self._handle_sig = handle, sig
+        self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_shake_rcnn_destroy, handle)
+        return handle
+
+    def forward(self, x, alphas=None):
+        x, al = self._prepare(x, alphas)
+        handle = self._get_handle(x.device)
+        B, T, _ = x.shape
+        lib = _lib.lib()
+        logits = torch.empty((B, T // 4, self.num_classes), dtype=torch.float32, device=x.device)
+        if B == 0 or T == 0:
+            return logits
+        ws_bytes = lib.sedmi_shake_rcnn_workspace_bytes(handle, B, T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sedmi_shake_rcnn_forward_f32(handle, _lib.ptr(x), B, T, al, _lib.ptr(logits), _lib.ptr(ws),
+                                                        ws_bytes, _lib.stream_ptr(x.device)),
+                       "sedmi_shake_rcnn_forward_f32")
+        return logits
+
+    def forward_cnn(self, x, alphas=None):
+        """The three ShakeCNNBlocks + transpose/flatten (models.py:126-134): [B, T/4, 6144]."""
+        x, al = self._prepare(x, alphas)
+        handle = self._get_handle(x.device)
+        B, T, _ = x.shape
+        lib = _lib.lib()
+        seq = torch.empty((B, T // 4, 6144), dtype=torch.float32, device=x.device)
+        if B == 0 or T == 0:
+            return seq
+        ws_bytes = lib.sedmi_shake_rcnn_workspace_bytes(handle, B, T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sedmi_shake_cnn_f32(handle, _lib.ptr(x), B, T, al, _lib.ptr(seq), _lib.ptr(ws), ws_bytes,
+                                               _lib.stream_ptr(x.device)), "sedmi_shake_cnn_f32")
+        return seq
+
+    def get_weak_logits(self, x):
+        # models.py:144-152, plain tensor ops on the (tiny) logits
+        return torch.mean(self.softmax(x) * self.sigmoid(x), dim=1)

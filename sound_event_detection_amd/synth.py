@@ -126,3 +126,90 @@ def synth_crnn_state_dict(seed: int = 0, nclass: int = 10, head_gain: float = 4.
             v = rng.uniform(-bound, bound, shape)
         sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
     return sd
+
+
+# ---------------------------------------------------------------------------
+# ShakeRCNN / ShakeTransformer (models.py:103-221)
+# ---------------------------------------------------------------------------
+SHAKE_BLOCKS = (("cnn1", 1, 16, 5), ("cnn2", 16, 32, 3), ("cnn3", 32, 64, 3))
+
+
+def _shake_cnn_spec():
+    spec = []
+    for name, cin, cout, k in SHAKE_BLOCKS:
+        spec += [(f"{name}.conv.weight", (2 * cout, cin, k, k)), (f"{name}.conv.bias", (2 * cout,))]
+        for bn, c in (("bn1", 2 * cout),):
+            spec += [(f"{name}.{bn}.weight", (c,)), (f"{name}.{bn}.bias", (c,)), (f"{name}.{bn}.running_mean", (c,)),
+                     (f"{name}.{bn}.running_var", (c,)), (f"{name}.{bn}.num_batches_tracked", ())]
+        for br in ("branch1", "branch2"):
+            spec += [(f"{name}.shake.{br}.weight", (cout, cout, 3, 3)), (f"{name}.shake.{br}.bias", (cout,))]
+        spec += [(f"{name}.bn2.weight", (cout,)), (f"{name}.bn2.bias", (cout,)), (f"{name}.bn2.running_mean", (cout,)),
+                 (f"{name}.bn2.running_var", (cout,)), (f"{name}.bn2.num_batches_tracked", ())]
+    return spec
+
+
+def shake_rcnn_state_dict_spec(num_classes: int = 10):
+    """Ordered (key, shape) list of ShakeRCNN's state_dict (models.py:105-121)."""
+    spec = _shake_cnn_spec()
+    for sfx in ("", "_reverse"):
+        spec += [(f"rnn.weight_ih_l0{sfx}", (3072, 6144)), (f"rnn.weight_hh_l0{sfx}", (3072, 1024)),
+                 (f"rnn.bias_ih_l0{sfx}", (3072,)), (f"rnn.bias_hh_l0{sfx}", (3072,))]
+    spec += [("layernorm.weight", (2048,)), ("layernorm.bias", (2048,)),
+             ("fc1.weight", (num_classes, 2048)), ("fc1.bias", (num_classes,))]
+    return spec
+
+
+def shake_transformer_state_dict_spec(num_classes: int = 10, layers: int = 6):
+    """Ordered (key, shape) list of ShakeTransformer's state_dict (models.py:185-202)."""
+    spec = _shake_cnn_spec()
+    spec += [("fc1.weight", (1024, 6144)), ("fc1.bias", (1024,))]
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        spec += [(p + "self_attn.in_proj_weight", (3072, 1024)), (p + "self_attn.in_proj_bias", (3072,)),
+                 (p + "self_attn.out_proj.weight", (1024, 1024)), (p + "self_attn.out_proj.bias", (1024,)),
+                 (p + "linear1.weight", (2048, 1024)), (p + "linear1.bias", (2048,)),
+                 (p + "linear2.weight", (1024, 2048)), (p + "linear2.bias", (1024,)),
+                 (p + "norm1.weight", (1024,)), (p + "norm1.bias", (1024,)),
+                 (p + "norm2.weight", (1024,)), (p + "norm2.bias", (1024,))]
+    spec += [("fc2.weight", (num_classes, 1024)), ("fc2.bias", (num_classes,))]
+    return spec
+
+
+def synth_shake_state_dict(spec, seed: int = 0, head_gain: float = 3.0):
+    """Deterministic weights for a Shake model: fan-in scaled uniform matrices,
+    BatchNorm / LayerNorm statistics near (0, 1), head scaled by ``head_gain``."""
+    rng = np.random.Generator(np.random.PCG64(4711 + int(seed)))
+    sd = {}
+    head_key = "fc2.weight" if any(k == "fc2.weight" for k, _ in spec) else "fc1.weight"
+    for key, shape in spec:
+        leaf = key.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[key] = torch.tensor(100, dtype=torch.int64)
+            continue
+        n = int(np.prod(shape)) if shape else 1
+        norm_like = ".bn" in key or "norm" in key
+        if norm_like and leaf == "weight":
+            v = rng.uniform(0.8, 1.2, n)
+        elif norm_like and leaf == "running_var":
+            v = rng.uniform(0.8, 1.2, n)
+        elif norm_like or leaf.startswith("bias") or leaf.endswith("bias"):
+            v = rng.uniform(-0.1, 0.1, n)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            bound = np.sqrt(3.0 / fan_in)
+            if ".conv." in key:
+                bound *= 1.5
+            if key == head_key:
+                bound *= head_gain
+            v = rng.uniform(-bound, bound, n)
+        sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
+    return sd
+
+
+def synth_shake_feats(seed: int, n_clips: int, n_frames: int = 1000, n_bins: int = 768) -> np.ndarray:
+    """[n_clips, n_frames, n_bins] float32 stand-in for the AST features the Shake models are fed
+    (feature_extraction.py:23,57): unit normal noise plus a slow per-bin drift, seeded."""
+    rng = np.random.Generator(np.random.PCG64(9000 + int(seed)))
+    x = rng.standard_normal((n_clips, n_frames, n_bins), dtype=np.float32)
+    drift = np.sin(np.arange(n_frames, dtype=np.float32)[:, None] * 0.02 + np.arange(n_bins, dtype=np.float32)[None] * 0.05)
+    return (x + 0.5 * drift).astype(np.float32)

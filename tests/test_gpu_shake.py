@@ -1,0 +1,89 @@
+"""ShakeRCNN HIP path (through the C ABI) against the reference's outputs and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sound_event_detection_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "shake_seed0.npz")
+ATOL_LOGITS = 1e-3      # logits; probabilities move by at most a quarter of this
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from sound_event_detection_amd.models import ShakeRCNN
+    m = ShakeRCNN(10, 0)
+    m.load_state_dict(synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0))
+    m.eval()
+    return m.cuda()
+
+
+def test_state_dict_keys_match_spec(model):
+    assert list(model.state_dict().keys()) == [k for k, _ in synth.shake_rcnn_state_dict_spec(10)]
+
+
+def test_cnn_blocks_small_vs_reference(model, gold):
+    x = torch.from_numpy(synth.synth_shake_feats(1, 2, 64)).cuda()
+    seq = model.forward_cnn(x, gold["rcnn_small_alphas"]).cpu().numpy()
+    ref = gold["cnn_small_seq"]
+    assert seq.shape == ref.shape
+    np.testing.assert_allclose(seq, ref, rtol=0, atol=2e-5)
+
+
+def test_rcnn_small_vs_reference(model, gold):
+    x = torch.from_numpy(synth.synth_shake_feats(1, 2, 64)).cuda()
+    got = model(x, gold["rcnn_small_alphas"]).cpu().numpy()
+    np.testing.assert_allclose(got, gold["rcnn_small_logits"], rtol=0, atol=ATOL_LOGITS)
+
+
+def test_rcnn_full_clip_vs_reference(model, gold):
+    x = torch.from_numpy(synth.synth_shake_feats(2, 1, 1000)).cuda()
+    got = model(x, gold["rcnn_full_alphas"]).cpu().numpy()
+    assert got.shape == (1, 250, 10)
+    np.testing.assert_allclose(got, gold["rcnn_full_logits"], rtol=0, atol=ATOL_LOGITS)
+
+
+def test_alpha_drawn_like_reference(model, gold):
+    # no alphas given: three torch.rand(1) draws, as models.py:91 does; seed 11 is the golden's seed
+    x = torch.from_numpy(synth.synth_shake_feats(1, 2, 64)).cuda()
+    torch.manual_seed(11)
+    got = model(x).cpu().numpy()
+    np.testing.assert_allclose(got, gold["rcnn_small_logits"], rtol=0, atol=ATOL_LOGITS)
+
+
+def test_ragged_batch_vs_oracle(model):
+    # 35 clips (two 16-clip passes + a remainder of 3, one partial 32-clip GRU tile), 8 frames
+    from oracle import shake
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    x = torch.from_numpy(synth.synth_shake_feats(5, 35, 8))
+    al = [0.25, 0.5, 0.75]
+    want = shake.shake_rcnn_forward(sd, x, al).numpy()
+    got = model(x.cuda(), al).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
+def test_clips_are_independent(model):
+    x = torch.from_numpy(synth.synth_shake_feats(6, 3, 16)).cuda()
+    al = [0.3, 0.6, 0.9]
+    all3 = model(x, al)
+    one = model(x[1:2].contiguous(), al)
+    assert torch.equal(all3[1:2], one)
+
+
+def test_rejects_bad_input(model):
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 10, 768, device="cuda"))
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 8, 128, device="cuda"))
+    from sound_event_detection_amd import _lib
+    with pytest.raises(_lib.SedmiError):
+        model(torch.zeros(1, 8, 768))
+    assert model(torch.zeros(0, 8, 768, device="cuda")).shape == (0, 2, 10)

@@ -1,0 +1,51 @@
+"""The Shake-model oracle against outputs of the reference's own classes
+(tests/golden/shake_seed0.npz, written by oracle/make_golden.py from models.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shake
+from sound_event_detection_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "shake_seed0.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def small():
+    return torch.from_numpy(synth.synth_shake_feats(1, 2, 64))
+
+
+def test_rcnn_small_matches_reference(gold, small):
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    got = shake.shake_rcnn_forward(sd, small, gold["rcnn_small_alphas"]).numpy()
+    np.testing.assert_allclose(got, gold["rcnn_small_logits"], rtol=0, atol=2e-5)
+    seq = shake.shake_cnn(sd, small, gold["rcnn_small_alphas"]).numpy()
+    np.testing.assert_allclose(seq, gold["cnn_small_seq"], rtol=0, atol=1e-6)
+
+
+def test_transformer_small_matches_reference(gold, small):
+    sd = synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0)
+    got = shake.shake_transformer_forward(sd, small, gold["transformer_small_alphas"]).numpy()
+    np.testing.assert_allclose(got, gold["transformer_small_logits"], rtol=0, atol=5e-5)
+
+
+def test_state_dict_specs_match_reference_key_schema():
+    # key schema of models.py:105-121 / :185-202 as listed by the reference's state_dict()
+    r = [k for k, _ in synth.shake_rcnn_state_dict_spec(10)]
+    assert len(r) == 3 * 16 + 8 + 4 and "cnn2.shake.branch2.bias" in r and "rnn.weight_hh_l0_reverse" in r
+    t = [k for k, _ in synth.shake_transformer_state_dict_spec(10)]
+    assert len(t) == 3 * 16 + 2 + 6 * 12 + 2 and "encoder.layers.5.norm2.bias" in t
+
+
+def test_alpha_changes_output(gold, small):
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    a = shake.shake_cnn(sd, small, [0.1, 0.1, 0.1])
+    b = shake.shake_cnn(sd, small, [0.9, 0.9, 0.9])
+    assert float((a - b).abs().max()) > 1e-3
