@@ -223,6 +223,50 @@ int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *model, const float *feats, int64
                         const float *alphas, float *seq, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
+ * ShakeTransformer eval-mode forward — replaces ShakeTransformer.forward
+ * (models.py:204-221): the same three ShakeCNNBlocks, Linear(6144, 1024),
+ * n_layers x torch.nn.TransformerEncoderLayer(d_model 1024, nhead 8,
+ * dim_feedforward 2048, ReLU, post-LayerNorm (eps 1e-5), batch_first; no mask,
+ * no positional encoding) (models.py:195-196), Linear(1024, n_class).
+ *
+ * Host float32 pointers in the state_dict layouts; layer i is
+ * encoder.layers.{i}.:  in_proj_w self_attn.in_proj_weight [3072,1024],
+ * in_proj_b [3072], out_proj_w self_attn.out_proj.weight [1024,1024],
+ * out_proj_b [1024], lin1_w linear1.weight [2048,1024], lin1_b [2048],
+ * lin2_w linear2.weight [1024,2048], lin2_b [1024], norm{1,2}_{w,b} [1024];
+ * fc1_w fc1.weight [1024,6144], fc2_w fc2.weight [n_class,1024].
+ * ------------------------------------------------------------------------ */
+#define SEDMI_SHAKE_MAX_LAYERS 12
+
+typedef struct sedmi_shake_transformer sedmi_shake_transformer;
+
+typedef struct sedmi_shake_encoder_layer_weights {
+    const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+    const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} sedmi_shake_encoder_layer_weights;
+
+typedef struct sedmi_shake_transformer_weights {
+    int n_class;
+    int n_layers;                       /* 6 in the reference (models.py:196) */
+    sedmi_shake_cnn_weights cnn;
+    const float *fc1_w, *fc1_b;
+    sedmi_shake_encoder_layer_weights layers[SEDMI_SHAKE_MAX_LAYERS];
+    const float *fc2_w, *fc2_b;
+} sedmi_shake_transformer_weights;
+
+/* ShakeTransformer(num_classes, dropout) + load_state_dict (models.py:185-202). */
+int sedmi_shake_transformer_create(sedmi_shake_transformer **out, const sedmi_shake_transformer_weights *w);
+int sedmi_shake_transformer_destroy(sedmi_shake_transformer *model);
+size_t sedmi_shake_transformer_workspace_bytes(const sedmi_shake_transformer *model, int64_t n_clips, int64_t T);
+
+/* feats [n_clips, T, 768] (device) -> logits [n_clips, T/4, n_class] (device);
+ * T a multiple of 4; alphas as for sedmi_shake_rcnn_forward_f32. */
+int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *model, const float *feats,
+                                        int64_t n_clips, int64_t T, const float *alphas, float *logits,
+                                        void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
  * Thresholding and event decoding.
  * ------------------------------------------------------------------------ */
 

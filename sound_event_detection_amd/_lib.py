@@ -53,6 +53,21 @@ class ShakeRcnnWeights(C.Structure):
                 ("ln_w", _FP), ("ln_b", _FP), ("fc_w", _FP), ("fc_b", _FP)]
 
 
+SHAKE_MAX_LAYERS = 12
+
+
+class ShakeEncoderLayerWeights(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w",
+                                                    "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w",
+                                                    "norm2_b")]
+
+
+class ShakeTransformerWeights(C.Structure):
+    _FP = C.POINTER(C.c_float)
+    _fields_ = [("n_class", C.c_int), ("n_layers", C.c_int), ("cnn", ShakeCnnWeights), ("fc1_w", _FP), ("fc1_b", _FP),
+                ("layers", ShakeEncoderLayerWeights * SHAKE_MAX_LAYERS), ("fc2_w", _FP), ("fc2_b", _FP)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -84,6 +99,10 @@ SIGNATURES = {
     "sedmi_shake_rcnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
     "sedmi_shake_rcnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
     "sedmi_shake_cnn_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
+    "sedmi_shake_transformer_create": (_I, [C.POINTER(_VP), C.POINTER(ShakeTransformerWeights)]),
+    "sedmi_shake_transformer_destroy": (_I, [_VP]),
+    "sedmi_shake_transformer_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
+    "sedmi_shake_transformer_forward_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
     "sedmi_threshold_i64": (_I, [_VP, _I64, _F, _I, _VP, _VP]),
     "sedmi_decode_workspace_bytes": (_SZ, [_I64, _I]),
     "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,

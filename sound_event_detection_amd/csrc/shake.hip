@@ -286,12 +286,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// C[M][N] = (A[M][K] . B) * oscale + bias, split-f16; B packed [K/16][2][N][16]; N, K % 128 == 0
+// C[M][N] = act((A[M][K] . B) * oscale + bias), act = identity or ReLU, split-f16; B packed [K/16][2][N][16]; N, K % 128 == 0
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float *__restrict__ A, long lda,
                                                            const uint4 *__restrict__ bpk, int N, int K,
                                                            const float *__restrict__ bias, float oscale,
-                                                           float *__restrict__ C, long ldc, long M) {
+                                                           float *__restrict__ C, long ldc, long M, int relu) {
     constexpr int KC = 128, PSB = KC * 2 + 16, PLANE = 128 * PSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
-                if (row < M) C[row * ldc + ncol + 32 * nt] = fmaf(acc[mt][nt][r], oscale, bv);
+                float v = fmaf(acc[mt][nt][r], oscale, bv);
+                if (relu) v = fmaxf(v, 0.f);
+                if (row < M) C[row * ldc + ncol + 32 * nt] = v;
             }
     }
 }
@@ -438,13 +440,14 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm(2048) -> LeakyReLU(0.01) -> Linear(2048, n_cls): one wave per row
+// [LayerNorm(D) -> LeakyReLU(0.01) ->] Linear(D, n_cls): one wave per row
 // ---------------------------------------------------------------------------
+template <int D, bool DO_LN>
 __global__ __launch_bounds__(256) void ln_head_kernel(const float *__restrict__ x, const float *__restrict__ lw,
                                                       const float *__restrict__ lb, const float *__restrict__ fw,
                                                       const float *__restrict__ fb, float *__restrict__ out,
                                                       long n_rows, int n_cls) {
-    constexpr int D = 2 * GB_H, PER = D / 64;
+    constexpr int PER = D / 64;
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -456,22 +459,24 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const float *__restrict__ 
         v[i] = xr[lane + 64 * i];
         s += v[i];
     }
+    if (DO_LN) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / D);
-    float q = 0.f;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / D);
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const float d = v[i] - mean;
-        q = fmaf(d, d, q);
-    }
+        for (int i = 0; i < PER; ++i) {
+            const float d = v[i] - mean;
+            q = fmaf(d, d, q);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * (1.0f / D) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const float n = (v[i] - mean) * rstd * lw[lane + 64 * i] + lb[lane + 64 * i];
-        v[i] = n > 0.f ? n : 0.01f * n;
+        for (int i = 0; i < PER; ++i) {
+            const float n = (v[i] - mean) * rstd * lw[lane + 64 * i] + lb[lane + 64 * i];
+            v[i] = n > 0.f ? n : 0.01f * n;
+        }
     }
     for (int c = 0; c < n_cls; ++c) {
         const float *wr = fw + static_cast<long>(c) * D;
@@ -494,7 +499,151 @@ __global__ __launch_bounds__(256) void to_reference_order_kernel(const float *__
     dst[i] = src[row * 6144 + f * 64 + c];
 }
 
+// ---------------------------------------------------------------------------
+// multi-head self-attention, head_dim 128, no mask (TransformerEncoderLayer, batch_first):
+// one workgroup = one (clip, head) x 128 queries, a wave = 32 queries; keys/values stream through
+// LDS 32 at a time with the running-max softmax.  Exact-f32 MFMAs (v_mfma_f32_32x32x2_f32): both
+// operands are activations, and attention is a few percent of the layer's work.
+// The score tile is computed transposed (rows = keys, columns = queries) so that a query's 32
+// scores sit in one lane pair: the softmax needs one cross-lane exchange, and the probabilities are
+// already laid out as the B operand of  O^T += V^T . P^T.
+// ---------------------------------------------------------------------------
+constexpr int AT_D = 128, AT_KB = 32, AT_LD = AT_D + 4;
+
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv,   // [clip*T + t][3*1024]
+                                                        float *__restrict__ out,         // [clip*T + t][1024]
+                                                        int T, float scale) {
+    __shared__ __attribute__((aligned(16))) float ks[AT_KB][AT_LD];
+    __shared__ __attribute__((aligned(16))) float vs[AT_KB][AT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int head = blockIdx.y;
+    const long row0 = static_cast<long>(blockIdx.z) * T;
+    const int q = blockIdx.x * 128 + wave * 32 + col32;
+    const float *base = qkv + row0 * 3072 + head * AT_D;
+
+    float qr[64];                       // this lane's query, k = 8g + 4*half + i  ->  qr[4g + i]
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < T) v = *reinterpret_cast<const float4 *>(base + static_cast<long>(q) * 3072 + 8 * g + 4 * half);
+        qr[4 * g] = v.x * scale; qr[4 * g + 1] = v.y * scale; qr[4 * g + 2] = v.z * scale; qr[4 * g + 3] = v.w * scale;
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int kb0 = 0; kb0 < T; kb0 += AT_KB) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, key = i >> 5, c4 = (i & 31) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (kb0 + key < T) {
+                const float *p = base + static_cast<long>(kb0 + key) * 3072 + c4;
+                kv = *reinterpret_cast<const float4 *>(p + 1024);
+                vv = *reinterpret_cast<const float4 *>(p + 2048);
+            }
+            *reinterpret_cast<float4 *>(&ks[key][c4]) = kv;
+            *reinterpret_cast<float4 *>(&vs[key][c4]) = vv;
+        }
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4 a = *reinterpret_cast<const float4 *>(&ks[col32][8 * g + 4 * half]);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qr[4 * g], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qr[4 * g + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qr[4 * g + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qr[4 * g + 3], s, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (kb0 + acc_row(r, half) >= T) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);            // finite: key kb0 < T is in every block
+        const float corr = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        l = fmaf(l, corr, psum);
+        m = m_new;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float *vrow = &vs[acc_row(j, half)][col32];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * nt], s[j], o[nt], 0, 0, 0);
+        }
+    }
+    if (q < T) {
+        const float inv = 1.0f / l;
+        float *op = out + (row0 + q) * 1024 + head * AT_D;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<float4 *>(op + 32 * nt + 8 * r4 + 4 * half) =
+                    make_float4(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv, o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv);
+    }
+}
+
+// out = LayerNorm(x + y) over rows of 1024 (post-LN residual), one wave per row; out may alias x
+__global__ __launch_bounds__(256) void add_ln_kernel(const float *x, const float *__restrict__ y,
+                                                     const float *__restrict__ w, const float *__restrict__ b,
+                                                     float *out, long n_rows) {
+    constexpr int D = 1024, PER = D / 256;
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + row * D + (lane + 64 * i) * 4);
+        const float4 c = *reinterpret_cast<const float4 *>(y + row * D + (lane + 64 * i) * 4);
+        v[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+        qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    const float rstd = rsqrtf(qq * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float4 ww = *reinterpret_cast<const float4 *>(w + (lane + 64 * i) * 4);
+        const float4 bb = *reinterpret_cast<const float4 *>(b + (lane + 64 * i) * 4);
+        *reinterpret_cast<float4 *>(out + row * D + (lane + 64 * i) * 4) =
+            make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                        (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+    }
+}
+
 constexpr int kShakeChunk = 16;     // clips per pass through the conv blocks (u1 is 49 MB per clip)
+constexpr int kMaxEncoderLayers = SEDMI_SHAKE_MAX_LAYERS;
 
 struct BlockDev {
     uint16_t *wa = nullptr, *wb = nullptr;      // packed split weights: conv A (blocks 2, 3), branches (all)
@@ -503,25 +652,55 @@ struct BlockDev {
     float *s2 = nullptr, *t2 = nullptr;         // second BatchNorm affine
 };
 
+struct ShakeCnnDev {
+    ShakeConv1Params *d_c1 = nullptr;
+    BlockDev blk[3];
+};
+
+// y = act(x . W^T + b) with W [N][K] row-major (torch Linear), packed for gemm_split_kernel
+struct LinearDev {
+    uint16_t *w = nullptr;
+    float *b = nullptr;
+    float oscale = 1.f;
+    int N = 0, K = 0;
+};
+
+struct EncoderLayerDev {
+    LinearDev in_proj, out_proj, lin1, lin2;
+    float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
+};
+
 }  // namespace
 
 struct sedmi_shake_rcnn {
     int n_class = 0;
-    ShakeConv1Params *d_c1 = nullptr;
-    BlockDev blk[3];
-    uint16_t *d_wih = nullptr, *d_whh = nullptr;
-    float wih_oscale = 1.f, whh_oscale = 1.f;
-    float *d_bi = nullptr, *d_bhn = nullptr, *d_lw = nullptr, *d_lb = nullptr, *d_fw = nullptr, *d_fb = nullptr;
+    ShakeCnnDev cnn;
+    LinearDev wih;                       // both directions: N = 2 * 3072
+    uint16_t *d_whh = nullptr;
+    float whh_oscale = 1.f;
+    float *d_bhn = nullptr, *d_lw = nullptr, *d_lb = nullptr, *d_fw = nullptr, *d_fb = nullptr;
+};
+
+struct sedmi_shake_transformer {
+    int n_class = 0, n_layers = 0;
+    ShakeCnnDev cnn;
+    LinearDev fc1;
+    EncoderLayerDev layers[kMaxEncoderLayers];
+    float *d_fw = nullptr, *d_fb = nullptr;
 };
 
 namespace {
 
 struct ShakeScratch {
-    float *u1, *y1, *u2, *y2, *u3, *seq, *gi, *rec, *h0, *h1;
+    float *u1, *y1, *u2, *y2, *u3, *seq;
+    float *gi, *rec, *h0, *h1;               // ShakeRCNN
+    float *x, *qkv, *att, *ff;               // ShakeTransformer
     size_t bytes;
 };
 
-ShakeScratch carve_shake(void *ws, long n, long T) {
+enum { SHAKE_CNN_ONLY = 0, SHAKE_RCNN = 1, SHAKE_TRANSFORMER = 2 };
+
+ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
     ShakeScratch sc{};
     size_t off = 0;
     auto take = [&](size_t n_floats) {
@@ -536,10 +715,17 @@ ShakeScratch carve_shake(void *ws, long n, long T) {
     sc.y2 = take(static_cast<size_t>(ch) * T4 * 192 * 32);
     sc.u3 = take(static_cast<size_t>(ch) * T4 * 192 * 64);
     sc.seq = take(static_cast<size_t>(n) * T4 * 6144);
-    sc.gi = take(static_cast<size_t>(n) * T4 * 6144);
-    sc.rec = take(static_cast<size_t>(n) * T4 * 2048);
-    sc.h0 = take(static_cast<size_t>(2) * n * GB_H);
-    sc.h1 = take(static_cast<size_t>(2) * n * GB_H);
+    if (kind == SHAKE_RCNN) {
+        sc.gi = take(static_cast<size_t>(n) * T4 * 6144);
+        sc.rec = take(static_cast<size_t>(n) * T4 * 2048);
+        sc.h0 = take(static_cast<size_t>(2) * n * GB_H);
+        sc.h1 = take(static_cast<size_t>(2) * n * GB_H);
+    } else if (kind == SHAKE_TRANSFORMER) {
+        sc.x = take(static_cast<size_t>(n) * T4 * 1024);
+        sc.qkv = take(static_cast<size_t>(n) * T4 * 3072);
+        sc.att = take(static_cast<size_t>(n) * T4 * 1024);
+        sc.ff = take(static_cast<size_t>(n) * T4 * 2048);
+    }
     sc.bytes = off;
     return sc;
 }
@@ -561,7 +747,7 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
     return SEDMI_OK;
 }
 
-int run_shake_cnn(const sedmi_shake_rcnn *m, const float *feats, long n, int T, const float *alphas, float *seq,
+int run_shake_cnn(const ShakeCnnDev *m, const float *feats, long n, int T, const float *alphas, float *seq,
                   const ShakeScratch &sc, hipStream_t s) {
     const int T2 = T / 2, T4 = T / 4;
     for (long c0 = 0; c0 < n; c0 += kShakeChunk) {
@@ -591,18 +777,22 @@ int run_shake_cnn(const sedmi_shake_rcnn *m, const float *feats, long n, int T, 
     return SEDMI_OK;
 }
 
+int launch_linear(const char *name, const LinearDev &L, const float *A, float *Cout, long rows, bool relu, hipStream_t s) {
+    const size_t lds = 2 * 128 * (128 * 2 + 16);
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    sedmi::ProfileScope prof(name, s, 2.0 * rows * L.N * static_cast<double>(L.K), 4.0 * rows * (L.N + static_cast<double>(L.K)));
+    hipLaunchKernelGGL(gemm_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), L.N / 128), dim3(256), lds, s,
+                       A, static_cast<long>(L.K), reinterpret_cast<const uint4 *>(L.w), L.N, L.K, L.b, L.oscale, Cout,
+                       static_cast<long>(L.N), rows, relu ? 1 : 0);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
 int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
     const long rows = n * T4;
-    {
-        const size_t lds = 2 * 128 * (128 * 2 + 16);
-        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        sedmi::ProfileScope prof("shake_gru_input_proj", s, 2.0 * rows * 6144.0 * 6144.0, 4.0 * rows * 2 * 6144.0);
-        hipLaunchKernelGGL(gemm_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6144 / 128), dim3(256),
-                           lds, s, seq, 6144L, reinterpret_cast<const uint4 *>(m->d_wih), 6144, 6144, m->d_bi,
-                           m->wih_oscale, sc.gi, 6144L, rows);
-        SEDMI_CHECK_LAUNCH();
-    }
+    int rc;
+    if ((rc = launch_linear("shake_gru_input_proj", m->wih, seq, sc.gi, rows, false, s))) return rc;
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));
     const size_t lds = 4 * 2 * 32 * ((GB_H / 4) * 2 + 16);
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_big_step_kernel),
@@ -619,27 +809,75 @@ int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, c
     return SEDMI_OK;
 }
 
-}  // namespace
+int run_encoder(const sedmi_shake_transformer *m, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
+    const long rows = n * T4;
+    const unsigned ln_grid = static_cast<unsigned>(sedmi::ceil_div(rows, 4));
+    int rc;
+    if ((rc = launch_linear("shake_tf_fc1", m->fc1, sc.seq, sc.x, rows, false, s))) return rc;
+    for (int i = 0; i < m->n_layers; ++i) {
+        const EncoderLayerDev &L = m->layers[i];
+        if ((rc = launch_linear("shake_tf_in_proj", L.in_proj, sc.x, sc.qkv, rows, false, s))) return rc;
+        {
+            sedmi::ProfileScope prof("shake_tf_attention", s, 4.0 * n * 8 * static_cast<double>(T4) * T4 * AT_D,
+                                     4.0 * rows * 4096.0);
+            hipLaunchKernelGGL(attention_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128)), 8, static_cast<unsigned>(n)),
+                               dim3(256), 0, s, sc.qkv, sc.att, T4, 1.0f / std::sqrt(static_cast<float>(AT_D)));
+            SEDMI_CHECK_LAUNCH();
+        }
+        if ((rc = launch_linear("shake_tf_out_proj", L.out_proj, sc.att, sc.ff, rows, false, s))) return rc;
+        {
+            sedmi::ProfileScope prof("shake_tf_add_ln", s, 8.0 * rows * 1024, 4.0 * rows * 3 * 1024.0);
+            hipLaunchKernelGGL(add_ln_kernel, dim3(ln_grid), dim3(256), 0, s, sc.x, sc.ff, L.n1w, L.n1b, sc.x, rows);
+            SEDMI_CHECK_LAUNCH();
+        }
+        if ((rc = launch_linear("shake_tf_ffn1", L.lin1, sc.x, sc.ff, rows, true, s))) return rc;
+        if ((rc = launch_linear("shake_tf_ffn2", L.lin2, sc.ff, sc.att, rows, false, s))) return rc;
+        {
+            sedmi::ProfileScope prof("shake_tf_add_ln", s, 8.0 * rows * 1024, 4.0 * rows * 3 * 1024.0);
+            hipLaunchKernelGGL(add_ln_kernel, dim3(ln_grid), dim3(256), 0, s, sc.x, sc.att, L.n2w, L.n2b, sc.x, rows);
+            SEDMI_CHECK_LAUNCH();
+        }
+    }
+    return SEDMI_OK;
+}
 
-extern "C" {
+// ---- host: weight repacking ---------------------------------------------------
 
-int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weights *w) {
-    SEDMI_REQUIRE(out && w, "null argument");
-    *out = nullptr;
-    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
-    const sedmi_shake_cnn_weights &c = w->cnn;
+int upload_floats(float **dev, const float *src, size_t n) {
+    return sedmi::upload(dev, std::vector<float>(src, src + n));
+}
+
+// Linear weight [N][K] (row-major) -> split planes; kmap(k) = source column of GEMM k index
+template <typename KMap>
+int make_linear(LinearDev &L, const float *w, const float *bias, int N, int K, KMap kmap) {
+    L.N = N;
+    L.K = K;
+    const int S = split_scale_exp(w, static_cast<size_t>(N) * K);
+    L.oscale = std::ldexp(1.0f, -S);
+    auto packed = pack_split(K / 16, N, S, [&](int ks, int k16, int n) {
+        return w[static_cast<size_t>(n) * K + kmap(ks * 16 + k16)];
+    });
+    int rc;
+    if ((rc = sedmi::upload(&L.w, packed))) return rc;
+    return upload_floats(&L.b, bias, N);
+}
+
+void free_linear(LinearDev &L) {
+    (void)hipFree(L.w);
+    (void)hipFree(L.b);
+    L = LinearDev();
+}
+
+int check_cnn_weights(const sedmi_shake_cnn_weights &c) {
     for (int i = 0; i < 3; ++i)
         SEDMI_REQUIRE(c.conv_w[i] && c.conv_b[i] && c.bn1_w[i] && c.bn1_b[i] && c.bn1_mean[i] && c.bn1_var[i] &&
                           c.br1_w[i] && c.br1_b[i] && c.br2_w[i] && c.br2_b[i] && c.bn2_w[i] && c.bn2_b[i] &&
                           c.bn2_mean[i] && c.bn2_var[i], "null weight pointer in block %d", i + 1);
-    for (int d = 0; d < 2; ++d)
-        SEDMI_REQUIRE(w->gru_w_ih[d] && w->gru_w_hh[d] && w->gru_b_ih[d] && w->gru_b_hh[d], "null GRU weight pointer");
-    SEDMI_REQUIRE(w->ln_w && w->ln_b && w->fc_w && w->fc_b, "null head weight pointer");
+    return SEDMI_OK;
+}
 
-    auto *m = new sedmi_shake_rcnn();
-    m->n_class = w->n_class;
+int create_shake_cnn(ShakeCnnDev &dev, const sedmi_shake_cnn_weights &c) {
     int rc = SEDMI_OK;
-    auto fail = [&](int code) { sedmi_shake_rcnn_destroy(m); return code; };
     static const int cin[3] = {1, 16, 32}, cout[3] = {16, 32, 64};
     const float eps = 1e-5f;
     for (int i = 0; i < 3; ++i) {
@@ -653,7 +891,7 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
             s2[k] = c.bn2_w[i][k] / std::sqrt(c.bn2_var[i][k] + eps);
             t2[k] = c.bn2_b[i][k] - c.bn2_mean[i][k] * s2[k];
         }
-        BlockDev &b = m->blk[i];
+        BlockDev &b = dev.blk[i];
         if (i == 0) {
             ShakeConv1Params p{};
             for (int k = 0; k < 32; ++k) {
@@ -661,9 +899,8 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
                 p.s[k] = s1[k];
                 p.t[k] = t1[k];
             }
-            if (hipMalloc(reinterpret_cast<void **>(&m->d_c1), sizeof(p)) != hipSuccess ||
-                hipMemcpy(m->d_c1, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess)
-                return fail(sedmi::set_error(SEDMI_EHIP, "uploading block 1 parameters failed"));
+            SEDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&dev.d_c1), sizeof(p)));
+            SEDMI_CHECK_HIP(hipMemcpy(dev.d_c1, &p, sizeof(p), hipMemcpyHostToDevice));
         } else {
             const int cch = ci >= 32 ? 32 : 16, ksp = cch / 16;
             const float *src = c.conv_w[i];
@@ -675,7 +912,7 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
             std::vector<float> es(n2);
             for (int k = 0; k < n2; ++k) es[k] = std::ldexp(s1[k], -S);
             if ((rc = sedmi::upload(&b.wa, wa)) || (rc = sedmi::upload(&b.es_a, es)) || (rc = sedmi::upload(&b.et_a, t1)))
-                return fail(rc);
+                return rc;
         }
         {   // both shake branches as one GEMM: columns [branch 1 | branch 2]
             const int cch = co >= 32 ? 32 : 16, ksp = cch / 16;
@@ -694,22 +931,59 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
             }
             if ((rc = sedmi::upload(&b.wb, wb)) || (rc = sedmi::upload(&b.es_b, es)) || (rc = sedmi::upload(&b.et_b, et)) ||
                 (rc = sedmi::upload(&b.s2, s2)) || (rc = sedmi::upload(&b.t2, t2)))
-                return fail(rc);
+                return rc;
         }
     }
-    {   // GRU input projection: GEMM K index is (freq, chan); the reference's is chan * 96 + freq
-        int S = 100;
-        for (int d = 0; d < 2; ++d) S = std::min(S, split_scale_exp(w->gru_w_ih[d], static_cast<size_t>(3072) * 6144));
-        auto wih = pack_split(6144 / 16, 6144, S, [&](int ks, int k16, int n) {
-            const int k = ks * 16 + k16, f = k / 64, ch = k % 64;
-            return w->gru_w_ih[n / 3072][static_cast<size_t>(n % 3072) * 6144 + ch * 96 + f];
-        });
-        m->wih_oscale = std::ldexp(1.0f, -S);
-        std::vector<float> bi(6144), bhn(2 * GB_H);
+    return SEDMI_OK;
+}
+
+void free_shake_cnn(ShakeCnnDev &dev) {
+    (void)hipFree(dev.d_c1);
+    for (auto &b : dev.blk) {
+        (void)hipFree(b.wa); (void)hipFree(b.wb); (void)hipFree(b.es_a); (void)hipFree(b.et_a);
+        (void)hipFree(b.es_b); (void)hipFree(b.et_b); (void)hipFree(b.s2); (void)hipFree(b.t2);
+    }
+    dev = ShakeCnnDev();
+}
+
+// GEMM k index of the sequence is (freq, chan); the reference flattens (chan, freq): chan * 96 + freq
+inline int seq_kmap(int k) { return (k % 64) * 96 + k / 64; }
+
+int shake_check(const void *m, int64_t n, int64_t T) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(n >= 0 && T >= 0 && T < (1 << 24) && n < (1LL << 31), "bad shape");
+    SEDMI_REQUIRE(T % 4 == 0, "T = %lld: the three pooling stages need a multiple of 4 frames", static_cast<long long>(T));
+    return SEDMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weights *w) {
+    SEDMI_REQUIRE(out && w, "null argument");
+    *out = nullptr;
+    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
+    int rc = check_cnn_weights(w->cnn);
+    if (rc) return rc;
+    for (int d = 0; d < 2; ++d)
+        SEDMI_REQUIRE(w->gru_w_ih[d] && w->gru_w_hh[d] && w->gru_b_ih[d] && w->gru_b_hh[d], "null GRU weight pointer");
+    SEDMI_REQUIRE(w->ln_w && w->ln_b && w->fc_w && w->fc_b, "null head weight pointer");
+
+    auto *m = new sedmi_shake_rcnn();
+    m->n_class = w->n_class;
+    auto fail = [&](int code) { sedmi_shake_rcnn_destroy(m); return code; };
+    if ((rc = create_shake_cnn(m->cnn, w->cnn))) return fail(rc);
+    {
+        // input projection of both directions as one [6144][6144] matrix; b_hh of the r and z gates
+        // folds into its bias, b_hn stays inside the reset gate product
+        std::vector<float> wcat(static_cast<size_t>(6144) * 6144), bi(6144), bhn(2 * GB_H);
         for (int d = 0; d < 2; ++d) {
+            std::memcpy(wcat.data() + static_cast<size_t>(d) * 3072 * 6144, w->gru_w_ih[d], sizeof(float) * 3072 * 6144);
             for (int n = 0; n < 3072; ++n) bi[d * 3072 + n] = w->gru_b_ih[d][n] + (n < 2 * GB_H ? w->gru_b_hh[d][n] : 0.f);
             for (int n = 0; n < GB_H; ++n) bhn[d * GB_H + n] = w->gru_b_hh[d][2 * GB_H + n];
         }
+        if ((rc = make_linear(m->wih, wcat.data(), bi.data(), 6144, 6144, seq_kmap))) return fail(rc);
         int Sh = 100;
         for (int d = 0; d < 2; ++d) Sh = std::min(Sh, split_scale_exp(w->gru_w_hh[d], static_cast<size_t>(3072) * GB_H));
         std::vector<uint16_t> whh;
@@ -722,12 +996,10 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
             whh.insert(whh.end(), blk.begin(), blk.end());
         }
         m->whh_oscale = std::ldexp(1.0f, -Sh);
-        std::vector<float> lw(w->ln_w, w->ln_w + 2048), lb(w->ln_b, w->ln_b + 2048);
-        std::vector<float> fw(w->fc_w, w->fc_w + static_cast<size_t>(w->n_class) * 2048), fb(w->fc_b, w->fc_b + w->n_class);
-        if ((rc = sedmi::upload(&m->d_wih, wih)) || (rc = sedmi::upload(&m->d_whh, whh)) ||
-            (rc = sedmi::upload(&m->d_bi, bi)) || (rc = sedmi::upload(&m->d_bhn, bhn)) ||
-            (rc = sedmi::upload(&m->d_lw, lw)) || (rc = sedmi::upload(&m->d_lb, lb)) ||
-            (rc = sedmi::upload(&m->d_fw, fw)) || (rc = sedmi::upload(&m->d_fb, fb)))
+        if ((rc = sedmi::upload(&m->d_whh, whh)) || (rc = sedmi::upload(&m->d_bhn, bhn)) ||
+            (rc = upload_floats(&m->d_lw, w->ln_w, 2048)) || (rc = upload_floats(&m->d_lb, w->ln_b, 2048)) ||
+            (rc = upload_floats(&m->d_fw, w->fc_w, static_cast<size_t>(w->n_class) * 2048)) ||
+            (rc = upload_floats(&m->d_fb, w->fc_b, w->n_class)))
             return fail(rc);
     }
     *out = m;
@@ -736,12 +1008,9 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
 
 int sedmi_shake_rcnn_destroy(sedmi_shake_rcnn *m) {
     if (!m) return SEDMI_OK;
-    (void)hipFree(m->d_c1);
-    for (auto &b : m->blk) {
-        (void)hipFree(b.wa); (void)hipFree(b.wb); (void)hipFree(b.es_a); (void)hipFree(b.et_a);
-        (void)hipFree(b.es_b); (void)hipFree(b.et_b); (void)hipFree(b.s2); (void)hipFree(b.t2);
-    }
-    (void)hipFree(m->d_wih); (void)hipFree(m->d_whh); (void)hipFree(m->d_bi); (void)hipFree(m->d_bhn);
+    free_shake_cnn(m->cnn);
+    free_linear(m->wih);
+    (void)hipFree(m->d_whh); (void)hipFree(m->d_bhn);
     (void)hipFree(m->d_lw); (void)hipFree(m->d_lb); (void)hipFree(m->d_fw); (void)hipFree(m->d_fb);
     delete m;
     return SEDMI_OK;
@@ -749,14 +1018,7 @@ int sedmi_shake_rcnn_destroy(sedmi_shake_rcnn *m) {
 
 size_t sedmi_shake_rcnn_workspace_bytes(const sedmi_shake_rcnn *m, int64_t n_clips, int64_t T) {
     if (!m || n_clips <= 0 || T < 4) return 0;
-    return carve_shake(nullptr, n_clips, T).bytes;
-}
-
-static int shake_check(const sedmi_shake_rcnn *m, int64_t n, int64_t T) {
-    SEDMI_REQUIRE(m != nullptr, "model is null");
-    SEDMI_REQUIRE(n >= 0 && T >= 0 && T < (1 << 24) && n < (1LL << 31), "bad shape");
-    SEDMI_REQUIRE(T % 4 == 0, "T = %lld: the three pooling stages need a multiple of 4 frames", static_cast<long long>(T));
-    return SEDMI_OK;
+    return carve_shake(nullptr, n_clips, T, SHAKE_RCNN).bytes;
 }
 
 int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *m, const float *feats, int64_t n, int64_t T, const float *alphas,
@@ -765,10 +1027,10 @@ int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *m, const float *feats, int64_t n
     if (rc) return rc;
     if (n == 0 || T == 0) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && seq_ref_order && ws, "null pointer");
-    ShakeScratch sc = carve_shake(ws, n, T);
+    ShakeScratch sc = carve_shake(ws, n, T, SHAKE_RCNN);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = run_shake_cnn(m, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
+    if ((rc = run_shake_cnn(&m->cnn, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
     const long rows = n * (T / 4);
     hipLaunchKernelGGL(to_reference_order_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows * 6144, 256))), dim3(256), 0,
                        s, sc.seq, seq_ref_order, rows);
@@ -782,16 +1044,94 @@ int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *m, const float *feats, 
     if (rc) return rc;
     if (n == 0 || T == 0) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
-    ShakeScratch sc = carve_shake(ws, n, T);
+    ShakeScratch sc = carve_shake(ws, n, T, SHAKE_RCNN);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T4 = static_cast<int>(T / 4);
-    if ((rc = run_shake_cnn(m, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
+    if ((rc = run_shake_cnn(&m->cnn, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
     if ((rc = run_shake_gru(m, sc.seq, n, T4, sc, s))) return rc;
     const long rows = n * T4;
     sedmi::ProfileScope prof("shake_ln_head", s, 2.0 * rows * 2048.0 * m->n_class, 4.0 * rows * (2048.0 + m->n_class));
-    hipLaunchKernelGGL(ln_head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s, sc.rec,
-                       m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class);
+    hipLaunchKernelGGL((ln_head_kernel<2048, true>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
+                       sc.rec, m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int sedmi_shake_transformer_create(sedmi_shake_transformer **out, const sedmi_shake_transformer_weights *w) {
+    SEDMI_REQUIRE(out && w, "null argument");
+    *out = nullptr;
+    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
+    SEDMI_REQUIRE(w->n_layers >= 0 && w->n_layers <= kMaxEncoderLayers, "n_layers %d out of range (max %d)", w->n_layers,
+                  kMaxEncoderLayers);
+    int rc = check_cnn_weights(w->cnn);
+    if (rc) return rc;
+    SEDMI_REQUIRE(w->fc1_w && w->fc1_b && w->fc2_w && w->fc2_b, "null fc1 / fc2 weight pointer");
+    for (int i = 0; i < w->n_layers; ++i) {
+        const sedmi_shake_encoder_layer_weights &l = w->layers[i];
+        SEDMI_REQUIRE(l.in_proj_w && l.in_proj_b && l.out_proj_w && l.out_proj_b && l.lin1_w && l.lin1_b && l.lin2_w &&
+                          l.lin2_b && l.norm1_w && l.norm1_b && l.norm2_w && l.norm2_b, "null weight pointer in encoder layer %d", i);
+    }
+    auto *m = new sedmi_shake_transformer();
+    m->n_class = w->n_class;
+    m->n_layers = w->n_layers;
+    auto fail = [&](int code) { sedmi_shake_transformer_destroy(m); return code; };
+    auto ident = [](int k) { return k; };
+    if ((rc = create_shake_cnn(m->cnn, w->cnn))) return fail(rc);
+    if ((rc = make_linear(m->fc1, w->fc1_w, w->fc1_b, 1024, 6144, seq_kmap))) return fail(rc);
+    for (int i = 0; i < w->n_layers; ++i) {
+        const sedmi_shake_encoder_layer_weights &l = w->layers[i];
+        EncoderLayerDev &L = m->layers[i];
+        if ((rc = make_linear(L.in_proj, l.in_proj_w, l.in_proj_b, 3072, 1024, ident)) ||
+            (rc = make_linear(L.out_proj, l.out_proj_w, l.out_proj_b, 1024, 1024, ident)) ||
+            (rc = make_linear(L.lin1, l.lin1_w, l.lin1_b, 2048, 1024, ident)) ||
+            (rc = make_linear(L.lin2, l.lin2_w, l.lin2_b, 1024, 2048, ident)) ||
+            (rc = upload_floats(&L.n1w, l.norm1_w, 1024)) || (rc = upload_floats(&L.n1b, l.norm1_b, 1024)) ||
+            (rc = upload_floats(&L.n2w, l.norm2_w, 1024)) || (rc = upload_floats(&L.n2b, l.norm2_b, 1024)))
+            return fail(rc);
+    }
+    if ((rc = upload_floats(&m->d_fw, w->fc2_w, static_cast<size_t>(w->n_class) * 1024)) ||
+        (rc = upload_floats(&m->d_fb, w->fc2_b, w->n_class)))
+        return fail(rc);
+    *out = m;
+    return SEDMI_OK;
+}
+
+int sedmi_shake_transformer_destroy(sedmi_shake_transformer *m) {
+    if (!m) return SEDMI_OK;
+    free_shake_cnn(m->cnn);
+    free_linear(m->fc1);
+    for (auto &L : m->layers) {
+        free_linear(L.in_proj); free_linear(L.out_proj); free_linear(L.lin1); free_linear(L.lin2);
+        (void)hipFree(L.n1w); (void)hipFree(L.n1b); (void)hipFree(L.n2w); (void)hipFree(L.n2b);
+    }
+    (void)hipFree(m->d_fw); (void)hipFree(m->d_fb);
+    delete m;
+    return SEDMI_OK;
+}
+
+size_t sedmi_shake_transformer_workspace_bytes(const sedmi_shake_transformer *m, int64_t n_clips, int64_t T) {
+    if (!m || n_clips <= 0 || T < 4) return 0;
+    return carve_shake(nullptr, n_clips, T, SHAKE_TRANSFORMER).bytes;
+}
+
+int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const float *feats, int64_t n, int64_t T,
+                                        const float *alphas, float *logits, void *ws, size_t ws_bytes, void *stream) {
+    int rc = shake_check(m, n, T);
+    if (rc) return rc;
+    if (n == 0 || T == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
+    SEDMI_REQUIRE(n <= 65535, "at most 65535 clips per call");
+    ShakeScratch sc = carve_shake(ws, n, T, SHAKE_TRANSFORMER);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T4 = static_cast<int>(T / 4);
+    if ((rc = run_shake_cnn(&m->cnn, feats, n, static_cast<int>(T), alphas, sc.seq, sc, s))) return rc;
+    if ((rc = run_encoder(m, n, T4, sc, s))) return rc;
+    const long rows = n * T4;
+    sedmi::ProfileScope prof("shake_tf_head", s, 2.0 * rows * 1024.0 * m->n_class, 4.0 * rows * (1024.0 + m->n_class));
+    hipLaunchKernelGGL((ln_head_kernel<1024, false>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
+                       sc.x, nullptr, nullptr, m->d_fw, m->d_fb, logits, rows, m->n_class);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

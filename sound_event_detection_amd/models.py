@@ -1,14 +1,17 @@
-"""ShakeRCNN on MI355X behind the reference's interface.
+"""ShakeRCNN and ShakeTransformer on MI355X behind the reference's interface.
 
 Mirrors /root/reference/models.py: ``ShakeRCNN(num_classes, dropout=0)``
 (:105-121), ``forward(x) -> logits [B, T/4, num_classes]`` (:124-142),
 ``get_weak_logits`` (:144-152) and the state_dict keys
 (``cnn{1,2,3}.{conv,bn1,shake.branch1,shake.branch2,bn2}.*``, ``rnn.*_l0[_reverse]``,
-``layernorm.*``, ``fc1.*``), so ``load_state_dict`` of a reference checkpoint works.
+``layernorm.*``, ``fc1.*``); ``ShakeTransformer(num_classes, dropout)`` (:185-202),
+``forward(x) -> logits`` (:204-221) with keys ``cnn*``, ``fc1.*``,
+``encoder.layers.{0..5}.*``, ``fc2.*`` — so ``load_state_dict`` of a reference
+checkpoint works for both.
 
 The module tree only owns tensors; ``forward`` packs them once into a
-``sedmi_shake_rcnn`` handle and runs the HIP kernels of csrc/shake.hip through
-the C ABI.  Inference only, CUDA (ROCm) tensors only, no CPU path.
+``sedmi_shake_rcnn`` / ``sedmi_shake_transformer`` handle and runs the HIP
+kernels of csrc/shake.hip through the C ABI.  Inference only, CUDA (ROCm) tensors only, no CPU path.
 
 ShakeShake mixing weight: in eval mode the reference draws ``a = torch.rand(1)``
 per block on every forward (:88-91).  ``forward`` does the same (CPU generator,
@@ -175,3 +178,66 @@ class ShakeRCNN(_ShakeBase):
     def get_weak_logits(self, x):
         # models.py:144-152, plain tensor ops on the (tiny) logits
         return torch.mean(self.softmax(x) * self.sigmoid(x), dim=1)
+
+
+class ShakeTransformer(_ShakeBase):
+    def __init__(self, num_classes, dropout):
+        super().__init__()
+        self.num_classes = int(num_classes)
+        self.dropout = nn.Dropout(dropout)
+        self._build_cnn(dropout)
+        self.flatten = nn.Flatten(start_dim=2)
+        self.fc1 = nn.Linear(6144, 1024)
+        encoder_layer = nn.TransformerEncoderLayer(d_model=1024, nhead=8, dropout=dropout, batch_first=True)
+        self.encoder = nn.TransformerEncoder(encoder_layer, num_layers=6)
+        self.fc2 = nn.Linear(1024, num_classes)
+        self.sigmoid = nn.Sigmoid()
+        self.softmax = nn.Softmax(dim=-1)
+        self.relu = nn.LeakyReLU()
+
+    def _get_handle(self, device):
+        sig = (device.index, self._signature())
+        if self._handle is not None and self._handle_sig == sig:
+            return self._handle
+        self._release()
+        sd = self._host_state()
+        fp = C.POINTER(C.c_float)
+
+        def p(key):
+            return C.cast(C.c_void_p(sd[key].data_ptr()), fp)
+
+        w = _lib.ShakeTransformerWeights()
+        w.n_class, w.n_layers = self.num_classes, len(self.encoder.layers)
+        self._fill_cnn(w.cnn, p)
+        w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b = p("fc1.weight"), p("fc1.bias"), p("fc2.weight"), p("fc2.bias")
+        for i in range(w.n_layers):
+            b, l = f"encoder.layers.{i}.", w.layers[i]
+            l.in_proj_w, l.in_proj_b = p(b + "self_attn.in_proj_weight"), p(b + "self_attn.in_proj_bias")
+            l.out_proj_w, l.out_proj_b = p(b + "self_attn.out_proj.weight"), p(b + "self_attn.out_proj.bias")
+            l.lin1_w, l.lin1_b = p(b + "linear1.weight"), p(b + "linear1.bias")
+            l.lin2_w, l.lin2_b = p(b + "linear2.weight"), p(b + "linear2.bias")
+            l.norm1_w, l.norm1_b = p(b + "norm1.weight"), p(b + "norm1.bias")
+            l.norm2_w, l.norm2_b = p(b + "norm2.weight"), p(b + "norm2.bias")
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().sedmi_shake_transformer_create(C.byref(handle), C.byref(w)),
+                       "sedmi_shake_transformer_create")
+        self._handle, self._handle_sig = handle, sig
+        self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_shake_transformer_destroy, handle)
+        return handle
+
+    def forward(self, x, alphas=None):
+        x, al = self._prepare(x, alphas)
+        handle = self._get_handle(x.device)
+        B, T, _ = x.shape
+        lib = _lib.lib()
+        logits = torch.empty((B, T // 4, self.num_classes), dtype=torch.float32, device=x.device)
+        if B == 0 or T == 0:
+            return logits
+        ws_bytes = lib.sedmi_shake_transformer_workspace_bytes(handle, B, T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sedmi_shake_transformer_forward_f32(handle, _lib.ptr(x), B, T, al, _lib.ptr(logits),
+                                                               _lib.ptr(ws), ws_bytes, _lib.stream_ptr(x.device)),
+                       "sedmi_shake_transformer_forward_f32")
+        return logits

@@ -87,3 +87,47 @@ def test_rejects_bad_input(model):
     with pytest.raises(_lib.SedmiError):
         model(torch.zeros(1, 8, 768))
     assert model(torch.zeros(0, 8, 768, device="cuda")).shape == (0, 2, 10)
+
+
+# ---------------------------------------------------------------- ShakeTransformer
+@pytest.fixture(scope="module")
+def tmodel():
+    from sound_event_detection_amd.models import ShakeTransformer
+    m = ShakeTransformer(10, 0.0)
+    m.load_state_dict(synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0))
+    m.eval()
+    return m.cuda()
+
+
+def test_transformer_state_dict_keys_match_spec(tmodel):
+    assert list(tmodel.state_dict().keys()) == [k for k, _ in synth.shake_transformer_state_dict_spec(10)]
+
+
+def test_transformer_small_vs_reference(tmodel, gold):
+    x = torch.from_numpy(synth.synth_shake_feats(1, 2, 64)).cuda()
+    got = tmodel(x, gold["transformer_small_alphas"]).cpu().numpy()
+    np.testing.assert_allclose(got, gold["transformer_small_logits"], rtol=0, atol=ATOL_LOGITS)
+
+
+def test_transformer_full_clip_vs_reference(tmodel, gold):
+    # 250 tokens: two query tiles per head, a partial last key block (250 = 7 * 32 + 26)
+    x = torch.from_numpy(synth.synth_shake_feats(2, 1, 1000)).cuda()
+    got = tmodel(x, gold["transformer_full_alphas"]).cpu().numpy()
+    assert got.shape == (1, 250, 10)
+    np.testing.assert_allclose(got, gold["transformer_full_logits"], rtol=0, atol=ATOL_LOGITS)
+
+
+def test_transformer_ragged_batch_vs_oracle(tmodel):
+    from oracle import shake
+    sd = synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0)
+    x = torch.from_numpy(synth.synth_shake_feats(7, 19, 36))       # 9 tokens per clip, 171 rows
+    al = [0.2, 0.7, 0.4]
+    want = shake.shake_transformer_forward(sd, x, al).numpy()
+    got = tmodel(x.cuda(), al).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
+def test_transformer_clips_are_independent(tmodel):
+    x = torch.from_numpy(synth.synth_shake_feats(8, 3, 16)).cuda()
+    al = [0.3, 0.6, 0.9]
+    assert torch.equal(tmodel(x, al)[2:3], tmodel(x[2:3].contiguous(), al))
