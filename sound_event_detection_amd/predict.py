@@ -1,0 +1,82 @@
+"""File-level prediction: audio files in, the reference's event table out.
+
+Counterpart of the prediction loop of /root/reference/training.py:328-365, which
+per file chops the audio into ``clip_length`` ms pieces (feature_extraction.py:35),
+zero-pads the last one (:41-42), runs mel extraction, the model and a D2H copy
+clip by clip (training.py:345-348), concatenates the frame predictions
+(:350) and decodes them with the file's duration (:353-358).  Here whole files
+are grouped into batches of clips that go through mel -> CRNN -> decode on the GPU
+in one pass (``SedPipeline``); a file's clips are decoded as one frame sequence
+with the reference's cutoff ``int(duration / block) + 1`` (evaluation.py:58).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import feature_extraction as fe
+from .pipeline import SedPipeline
+
+
+def predict_files(model, test_files, dataset_location, dataset, clip_length, n_fft, n_mels, hop_length, win_length,
+                  id2cls, block_length, decision_threshold=0.5, apply_sigmoid=False, *, device=None,
+                  audio_loader=None, audio_duration=None, batch_clips=1024, median_window=1, return_probs=False):
+    """Events of every file as ``(file, onset_s, offset_s, label)`` tuples with
+    float64 times, files in input order, class-major inside a file
+    (evaluation.py:61-78).  With ``return_probs`` also {file: ndarray
+    [clips * frames, n_cls]} of the concatenated frame predictions."""
+    sr = fe.sampling_rates[dataset]
+    clip_s = 0.001 * clip_length
+    n_clip = int(sr * clip_s)
+    device = torch.device(device if device is not None else "cuda")
+    loader = audio_loader or fe._load_wav
+    get_dur = audio_duration or fe._wav_duration
+    pipe = SedPipeline(model, sr=sr, n_fft=n_fft, n_mels=n_mels, hop_length=hop_length, win_length=win_length,
+                       block_length=block_length, decision_threshold=decision_threshold,
+                       apply_sigmoid=apply_sigmoid, median_window=median_window)
+    block_s = float(block_length) / 1000
+    predictions, probs_out = [], {}
+    group = []          # (file, duration, [clips])
+
+    def flush():
+        if not group:
+            return
+        y = torch.from_numpy(np.stack([c for _, _, clips in group for c in clips])).to(device)
+        counts = [len(clips) for _, _, clips in group]
+        cutoffs = [int(dur / block_s) + 1 for _, dur, _ in group]              # evaluation.py:58
+        out = pipe.run(y, clips_per_recording=counts, cutoffs=cutoffs)
+        names = [f for f, _, _ in group]
+        predictions.extend(pipe.events(out, id2cls, names))
+        if return_probs:
+            p = out["probs"].cpu().numpy()
+            o = 0
+            for f, n in zip(names, counts):
+                probs_out[f] = p[o:o + n].reshape(-1, p.shape[-1])
+                o += n
+        group.clear()
+
+    n_pending = 0
+    for test_file in test_files:
+        path = dataset_location + dataset + '/' + test_file                      # training.py:352
+        duration = get_dur(path)
+        clips = []
+        for i in range(int(np.ceil(duration / clip_s))):                         # feature_extraction.py:35
+            clip = np.asarray(loader(path, sr, i * clip_s, clip_s), dtype=np.float32)
+            if len(clip) < n_clip:
+                clip = np.concatenate([clip, np.zeros(n_clip - len(clip), np.float32)])
+            clips.append(clip[:n_clip])
+        if not clips:
+            continue
+        if n_pending and n_pending + len(clips) > batch_clips:
+            flush()
+            n_pending = 0
+        group.append((test_file.replace('\\', '/'), duration, clips))
+        n_pending += len(clips)
+    flush()
+    return (predictions, probs_out) if return_probs else predictions
+
+
+def write_predictions_tsv(predictions, path):
+    """The table of training.py:364-365: header ``filename onset offset event_label``, tab separated."""
+    import pandas as pd
+    pd.DataFrame(predictions, columns=['filename', 'onset', 'offset', 'event_label']).to_csv(path, sep='\t', index=False)
