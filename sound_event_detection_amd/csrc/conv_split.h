@@ -280,26 +280,46 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
 
 // C[M][N] = A[M][K] . B + bias with the same split-f16 arithmetic (GRU input projections).
 // A row-major f32; B packed [K/16][2][N][16] f16 (hi, lo) pre-scaled by 2^S; out = acc * oscale + bias.
-// Workgroup tile 128 x 128, four waves as 2 x 2, K staged 128 at a time as hi/lo planes.
-template <int N, int K>
-__global__ __launch_bounds__(256, 2) void linear_split_kernel(const float *__restrict__ A, const uint4 *__restrict__ bpk,
-                                                             const float *__restrict__ bias, float oscale,
-                                                             float *__restrict__ C, long M) {
-    constexpr int KC = 128, PSB = KC * 2 + 16, PLANE = 128 * PSB;
+// A workgroup owns 128 rows: it stages them ONCE as hi/lo planes for the whole K, then walks the N
+// columns 64*WN at a time (2 x WN waves; WN = 4 where the planes leave room for one workgroup per
+// CU only, so that it still brings two waves per SIMD) with no barrier in that loop, so the stores of one
+// column block drain while the next block's MFMAs run.  The output is 3-6x the input here, so the
+// kernel is bounded by the rate at which C can be written.
+template <int N, int K, int WN>
+__global__ __launch_bounds__(128 * WN, (K <= 128 ? 2 : 1)) void linear_split_kernel(const float *__restrict__ A,
+                                                                             const uint4 *__restrict__ bpk,
+                                                                             const float *__restrict__ bias, float oscale,
+                                                                             float *__restrict__ C, long M) {
+    constexpr int PSB = K * 2 + 16, PLANE = 128 * PSB;
+    constexpr int NTHR = 128 * WN, NB = 64 * WN;
+    static_assert(N % NB == 0 && K % 64 == 0, "unsupported linear geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col32 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const long m0 = static_cast<long>(blockIdx.x) * 128;
-    const int ncol = blockIdx.y * 128 + wn * 64 + col32;
-    f32x16 acc[2][2];
+    constexpr int KC = 64, NLD = 128 * (KC / 4) / NTHR;    // staged 64 columns at a time
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        float4 v[NLD];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + NTHR * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) v[j] = *reinterpret_cast<const float4 *>(A + (m0 + r) * K + k0 + c);
+        }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + NTHR * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
+            uint2 hi, lo;
+            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
+            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(plane_h + r * PSB + (k0 + c) * 2) = hi;
+            *reinterpret_cast<uint2 *>(plane_l + r * PSB + (k0 + c) * 2) = lo;
+        }
+    }
+    __syncthreads();
     const char *ah[2], *al[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -307,39 +327,27 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float *__res
         ah[mt] = plane_h + off;
         al[mt] = plane_l + off;
     }
-    const uint4 *bp = bpk + ncol * 2 + half;
-    constexpr int NLD = 128 * (KC / 4) / 256;
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        float4 v[NLD];
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) v[j] = *reinterpret_cast<const float4 *>(A + (m0 + r) * K + k0 + c);
-        }
-        if (k0) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
-            uint2 hi, lo;
-            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
-            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
-            *reinterpret_cast<uint2 *>(plane_h + r * PSB + c * 2) = hi;
-            *reinterpret_cast<uint2 *>(plane_l + r * PSB + c * 2) = lo;
-        }
-        __syncthreads();
-        split_gemm<2, 2, KC / 16>(acc, ah, al, bp + static_cast<long>(k0 / 16) * (N * 4), N,
-                                  [](int i) { return i * 32; });
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float bv = bias[ncol + 32 * nt];
+#pragma unroll 1
+    for (int nb = 0; nb < N / NB; ++nb) {
+        const int ncol = nb * NB + wn * 64 + col32;
+        f32x16 acc[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
-                if (row < M) C[row * N + ncol + 32 * nt] = fmaf(acc[mt][nt][r], oscale, bv);
-            }
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        split_gemm<2, 2, K / 16>(acc, ah, al, bpk + ncol * 2 + half, N, [](int i) { return i * 32; });
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = bias[ncol + 32 * nt];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
+                    if (row < M) C[row * N + ncol + 32 * nt] = fmaf(acc[mt][nt][r], oscale, bv);
+                }
+        }
     }
 }

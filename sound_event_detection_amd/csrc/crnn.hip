@@ -428,6 +428,95 @@ __global__ __launch_bounds__(256, 1) void gru_kernel(
     }
 }
 
+// The same recurrence with the h . W_hh^T product in split-f16 arithmetic: W_hh sits in registers as
+// f16 (hi, lo) B fragments (192 VGPRs, as many as the f32 form), h goes through LDS as two f16 planes,
+// and a step costs 72 f16 MFMAs (2304 issue cycles) instead of 192 f32 MFMAs (12288).
+constexpr int GRU_PSB = GRU_H * 2 + 16;      // bytes per clip row of one h plane
+
+__global__ __launch_bounds__(256, 1) void gru_split_kernel(
+    const float *__restrict__ gi,      // [clip][T][2][3H]
+    const uint4 *__restrict__ whh,     // packed split [2][H/16][2 planes][3H][16] f16, pre-scaled by 2^S
+    float whh_oscale,                  // 2^-S
+    const float *__restrict__ bhn,     // [2][H]
+    float *__restrict__ out,           // [clip][T][2H]
+    long n_clips, int T) {
+    __shared__ __attribute__((aligned(16))) char hs[2][2][GRU_NB * GRU_PSB];     // [buffer][plane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const int dir = blockIdx.y;
+    const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;
+    const int j = 32 * wave + col32;                  // hidden unit owned by this lane
+
+    f16x8 wh[3][GRU_H / 16], wl[3][GRU_H / 16];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 16; ++ks) {
+            const uint4 *p = whh + ((static_cast<long>(dir) * (GRU_H / 16) + ks) * 2 * (3 * GRU_H) + g * GRU_H + j) * 2 + half;
+            wh[g][ks] = __builtin_bit_cast(f16x8, p[0]);
+            wl[g][ks] = __builtin_bit_cast(f16x8, p[2 * 3 * GRU_H]);
+        }
+    const float b_hn = bhn[dir * GRU_H + j];
+
+    for (int i = tid; i < static_cast<int>(sizeof(hs) / 4); i += 256) reinterpret_cast<unsigned *>(&hs[0][0][0])[i] = 0u;
+    float hprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hprev[r] = 0.f;
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        float gir[16], giz[16], gin[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long b = b0 + acc_row(r, half);
+            gir[r] = giz[r] = gin[r] = 0.f;
+            if (b < n_clips) {
+                const float *p = gi + ((b * T + t) * 2 + dir) * (3 * GRU_H) + j;
+                gir[r] = p[0];
+                giz[r] = p[GRU_H];
+                gin[r] = p[2 * GRU_H];
+            }
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        const char *ah = &hs[cur][0][col32 * GRU_PSB + 16 * half], *al = &hs[cur][1][col32 * GRU_PSB + 16 * half];
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 16; ++ks) {
+            const f16x8 vah = *reinterpret_cast<const f16x8 *>(ah + ks * 32);
+            const f16x8 val = *reinterpret_cast<const f16x8 *>(al + ks * 32);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val, wh[g][ks], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah, wl[g][ks], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah, wh[g][ks], acc[g], 0, 0, 0);
+        }
+        char *nh = &hs[cur ^ 1][0][0], *nl = &hs[cur ^ 1][1][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float rg = sigmoidf_fast(fmaf(acc[0][r], whh_oscale, gir[r]));
+            const float zg = sigmoidf_fast(fmaf(acc[1][r], whh_oscale, giz[r]));
+            const float ng = tanhf_fast(fmaf(rg, fmaf(acc[2][r], whh_oscale, b_hn), gin[r]));
+            const float hn = fmaf(zg, hprev[r] - ng, ng);          // (1 - z) * n + z * h
+            hprev[r] = hn;
+            const int row = acc_row(r, half);
+            _Float16 hi, lo;
+            split_f16(hn, hi, lo);
+            *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
+            *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
+            const long b = b0 + row;
+            if (b < n_clips) out[(b * T + t) * (2 * GRU_H) + dir * GRU_H + j] = hn;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // strong head: probs = sigmoid(x . Wd^T + bd), x [rows][256]
 // ---------------------------------------------------------------------------
@@ -462,6 +551,63 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
     }
 }
 
+// The same head for n_cls <= 32 (every configuration the reference trains): the 64 rows of a block
+// are fetched with 16 float4 loads per thread that are all in flight together, rows sit in LDS at a
+// 260-float stride (ds_read_b128 by 16 lanes sweeps all banks once), the weights sit in LDS too and
+// are read as broadcasts; a thread owns one row and every fourth class.
+constexpr int HEAD_XS = HEAD_K + 4;
+constexpr int HEAD_MAX_SMALL = 32;
+
+__global__ __launch_bounds__(256, 2) void head_small_kernel(const float *__restrict__ x, const float *__restrict__ wd,
+                                                            const float *__restrict__ bd, float *__restrict__ probs,
+                                                            long n_rows, int n_cls) {
+    extern __shared__ __attribute__((aligned(16))) float head_lds[];
+    float *xs = head_lds;                              // [64][HEAD_XS]
+    float *ws = head_lds + HEAD_ROWS * HEAD_XS;        // [n_cls][HEAD_K]
+    const int tid = threadIdx.x;
+    const long r0 = static_cast<long>(blockIdx.x) * HEAD_ROWS;
+    constexpr int NLD = HEAD_ROWS * (HEAD_K / 4) / 256;
+    float4 v[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + 256 * j, r = i / (HEAD_K / 4), c4 = (i % (HEAD_K / 4)) * 4;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < n_rows) v[j] = *reinterpret_cast<const float4 *>(x + (r0 + r) * HEAD_K + c4);
+    }
+    for (int i = tid; i < n_cls * (HEAD_K / 4); i += 256)
+        reinterpret_cast<float4 *>(ws)[i] = reinterpret_cast<const float4 *>(wd)[i];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + 256 * j, r = i / (HEAD_K / 4), c4 = (i % (HEAD_K / 4)) * 4;
+        *reinterpret_cast<float4 *>(xs + r * HEAD_XS + c4) = v[j];
+    }
+    __syncthreads();
+    const int r = tid & 63, cg = tid >> 6;
+    constexpr int NC = HEAD_MAX_SMALL / 4;
+    float acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = 0.f;
+    const float *xr = xs + r * HEAD_XS;
+    for (int k = 0; k < HEAD_K; k += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(xr + k);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = cg + 4 * q;
+            if (c < n_cls) {                           // wave-uniform
+                const float4 w = *reinterpret_cast<const float4 *>(ws + c * HEAD_K + k);
+                acc[q] = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, acc[q]))));
+            }
+        }
+    }
+    if (r0 + r < n_rows) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = cg + 4 * q;
+            if (c < n_cls) probs[(r0 + r) * n_cls + c] = sigmoidf_fast(acc[q] + bd[c]);
+        }
+    }
+}
+
 constexpr int kCnnChunk = 512;      // clips per pass through the conv stack (bounds the scratch)
 
 }  // namespace
@@ -477,6 +623,8 @@ struct sedmi_crnn {
     float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {};
     uint16_t *d_wihs[2] = {};          // split-f16 GRU input-projection weights
     float wih_oscale[2] = {1.f, 1.f};
+    uint16_t *d_whhs[2] = {};          // split-f16 GRU recurrent weights, both directions
+    float whh_oscale[2] = {1.f, 1.f};
     int precision = SEDMI_PRECISION_SPLIT_F16;
     float *d_wih[2] = {}, *d_bi[2] = {}, *d_whh[2] = {}, *d_bhn[2] = {};
     float *d_wd = nullptr, *d_bd = nullptr;
@@ -602,18 +750,19 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj_split<128>" : "gru_input_proj_split<256>", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
-            const dim3 grid(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6);
-            const size_t lds2 = 2 * 128 * (128 * 2 + 16);
+            const dim3 grid(static_cast<unsigned>(sedmi::ceil_div(rows, 128)));
             const uint4 *wsp = reinterpret_cast<const uint4 *>(m->d_wihs[layer]);
             if (layer == 0) {
-                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 128>),
+                const size_t lds2 = 2 * 128 * (128 * 2 + 16);
+                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 128, 2>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
-                hipLaunchKernelGGL((linear_split_kernel<768, 128>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
+                hipLaunchKernelGGL((linear_split_kernel<768, 128, 2>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
                                    m->wih_oscale[layer], gi, rows);
             } else {
-                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 256>),
+                const size_t lds2 = 2 * 128 * (256 * 2 + 16);
+                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 256, 4>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
-                hipLaunchKernelGGL((linear_split_kernel<768, 256>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
+                hipLaunchKernelGGL((linear_split_kernel<768, 256, 4>), grid, dim3(512), lds2, s, in, wsp, m->d_bi[layer],
                                    m->wih_oscale[layer], gi, rows);
             }
         } else {
@@ -627,9 +776,15 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
         {
             sedmi::ProfileScope prof("gru_kernel", s, 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
                                      4.0 * rows * (6.0 * GRU_H + 2.0 * GRU_H));
-            hipLaunchKernelGGL(gru_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2), dim3(256),
-                               0, s, gi, reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer],
-                               outs[layer], n_clips, Tp);
+            const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
+            if (m->precision == SEDMI_PRECISION_SPLIT_F16)
+                hipLaunchKernelGGL(gru_split_kernel, ggrid, dim3(256), 0, s, gi,
+                                   reinterpret_cast<const uint4 *>(m->d_whhs[layer]), m->whh_oscale[layer],
+                                   m->d_bhn[layer], outs[layer], n_clips, Tp);
+            else
+                hipLaunchKernelGGL(gru_kernel, ggrid, dim3(256), 0, s, gi,
+                                   reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer], outs[layer],
+                                   n_clips, Tp);
         }
         SEDMI_CHECK_LAUNCH();
         in = outs[layer];
@@ -762,6 +917,18 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
             });
             m->wih_oscale[l] = std::ldexp(1.0f, -S);
             if ((rc = sedmi::upload(&m->d_wihs[l], wihs))) return fail(rc);
+            int Sh = 100;
+            for (int d = 0; d < 2; ++d) Sh = std::min(Sh, split_scale_exp(w->gru_w_hh[l][d], static_cast<size_t>(3) * GRU_H * GRU_H));
+            std::vector<uint16_t> whhs;
+            for (int d = 0; d < 2; ++d) {
+                const float *src = w->gru_w_hh[l][d];
+                auto blk = pack_split(GRU_H / 16, 3 * GRU_H, Sh, [&](int ks, int k16, int n) {
+                    return src[static_cast<size_t>(n) * GRU_H + ks * 16 + k16];
+                });
+                whhs.insert(whhs.end(), blk.begin(), blk.end());
+            }
+            m->whh_oscale[l] = std::ldexp(1.0f, -Sh);
+            if ((rc = sedmi::upload(&m->d_whhs[l], whhs))) return fail(rc);
         }
         if ((rc = sedmi::upload(&m->d_wih[l], wih)) || (rc = sedmi::upload(&m->d_bi[l], bi)) ||
             (rc = sedmi::upload(&m->d_whh[l], whh)) || (rc = sedmi::upload(&m->d_bhn[l], bhn)))
@@ -786,6 +953,7 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
     }
     for (int l = 0; l < 2; ++l) {
         (void)hipFree(m->d_wihs[l]);
+        (void)hipFree(m->d_whhs[l]);
         (void)hipFree(m->d_wih[l]); (void)hipFree(m->d_bi[l]); (void)hipFree(m->d_whh[l]); (void)hipFree(m->d_bhn[l]);
     }
     (void)hipFree(m->d_wd); (void)hipFree(m->d_bd);
@@ -837,11 +1005,21 @@ int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, f
     SEDMI_REQUIRE(m != nullptr && n_rows >= 0, "bad argument");
     if (n_rows == 0) return SEDMI_OK;
     SEDMI_REQUIRE(rec && probs, "null data pointer");
+    sedmi::ProfileScope prof("head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
+                             4.0 * n_rows * (HEAD_K + m->n_class));
+    if (m->n_class <= HEAD_MAX_SMALL) {
+        const size_t lds = sizeof(float) * (HEAD_ROWS * HEAD_XS + m->n_class * HEAD_K);
+        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_small_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(head_small_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
+                           static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
+                           m->n_class);
+        SEDMI_CHECK_LAUNCH();
+        return SEDMI_OK;
+    }
     const size_t lds = sizeof(float) * HEAD_ROWS * (HEAD_K + 1);
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    sedmi::ProfileScope prof("head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
-                             4.0 * n_rows * (HEAD_K + m->n_class));
     hipLaunchKernelGGL(head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
                        static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
                        m->n_class);

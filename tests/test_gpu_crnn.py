@@ -129,3 +129,15 @@ def test_split_f16_tracks_f32_on_a_large_batch():
     m.conv_precision = "split_f16"
     b = m(x)
     assert float((a - b).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("ncls", [1, 4, 32, 33, 92])
+def test_class_counts_cover_both_head_kernels(ncls):
+    # <= 32 classes: weights in LDS; more: scalar-load variant
+    m, sd = _model(2, ncls)
+    rng = np.random.Generator(np.random.PCG64(ncls))
+    x = rng.gamma(0.5, 2.0, (3, 70, 128)).astype(np.float32)
+    got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ocrnn.crnn_forward(sd, torch.from_numpy(x)).numpy()
+    assert got.shape == want.shape == (3, 35, ncls)
+    assert np.abs(got - want).max() < PROB_TOL
