@@ -79,38 +79,31 @@ __device__ __forceinline__ void mma_block(f32x16 (&acc)[2][NT], const float *a0,
 // ---------------------------------------------------------------------------
 // block 0: 1 -> 16 channels, pool (2,2)
 // ---------------------------------------------------------------------------
+// Both halves of the gated unit are affine in the 3x3 input patch p of a position:
+//   z   = s * (W p) + t                       (conv, bias, BatchNorm)
+//   lin = G z + gb = (G diag(s) W) p + (G t + gb)   (the GLU's 16 x 16 linear)
+// so the host folds them into two 16 x 9 matrices (in float64) and the kernel never forms G z.
 struct Conv0Params {
-    float w[16][9];      // conv weight [co][ky*3+kx]
-    float s[16], t[16];  // z = conv * s + t  (bias and BatchNorm folded)
-    float g[16][16];     // GLU linear weight [co][ci]
-    float gb[16];
+    float wz[16][9];     // s[co] * conv weight [co][ky*3+kx]
+    float wl[16][9];     // (G diag(s) W)[co][tap]
+    float t[16], b2[16]; // z bias, lin bias
 };
 
 // Weights sit in LDS as float4 rows per output channel (every lane reads the same address: a
-// broadcast, no bank conflict): [co][0..2] = 9 taps (+3 pad), [co][3..6] = GLU row, [co][7] = (s, t, gb, 0).
+// broadcast, no bank conflict): [co][0..4] = 9 z taps, 9 lin taps, t, b2.
 __global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__ x, const Conv0Params *__restrict__ prm,
                                                     float *__restrict__ y, long n_clips, int T, int F, int Tp) {
     // x [clip][T][F], y [clip][Tp][F/2][16]
-    __shared__ float4 wsm[16][8];
-    if (threadIdx.x < 128) {
-        const int co = threadIdx.x >> 3, j = threadIdx.x & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < 3) {
-            v.x = prm->w[co][4 * j];
-            if (4 * j + 1 < 9) { v.y = prm->w[co][4 * j + 1]; v.z = prm->w[co][4 * j + 2]; v.w = prm->w[co][4 * j + 3]; }
-        } else if (j < 7) {
-            v = make_float4(prm->g[co][4 * (j - 3)], prm->g[co][4 * (j - 3) + 1], prm->g[co][4 * (j - 3) + 2],
-                            prm->g[co][4 * (j - 3) + 3]);
-        } else {
-            v = make_float4(prm->s[co], prm->t[co], prm->gb[co], 0.f);
-        }
-        wsm[co][j] = v;
+    __shared__ float wsm[16][20];
+    for (int i = threadIdx.x; i < 16 * 20; i += 256) {
+        const int co = i / 20, j = i - co * 20;
+        wsm[co][j] = j < 9 ? prm->wz[co][j] : (j < 18 ? prm->wl[co][j - 9] : (j == 18 ? prm->t[co] : prm->b2[co]));
     }
     __syncthreads();
     const int Fp = F / 2;
     const long total = n_clips * Tp * Fp;
     // one output position per thread, no grid-stride loop: with a loop the weight reads are
-    // loop-invariant and the compiler hoists all 448 of them into registers
+    // loop-invariant and the compiler hoists all of them into registers
     const long idx = blockIdx.x * 256L + threadIdx.x;
     if (idx < total) {
         const int w2 = static_cast<int>(idx % Fp);
@@ -128,40 +121,31 @@ __global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__
                 patch[r][c] = (hr >= 0 && hr < T && wc >= 0 && wc < F) ? xb[static_cast<long>(hr) * F + wc] : 0.f;
             }
         }
-        float z[4][16];
-#pragma unroll
-        for (int co = 0; co < 16; ++co) {
-            const float4 wa = wsm[co][0], wb = wsm[co][1], wc4 = wsm[co][2], st = wsm[co][7];
-            const float wv[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc4.x};
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) a[p] = fmaf(patch[(p >> 1) + k / 3][(p & 1) + k % 3], wv[k], a[p]);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) z[p][co] = fmaf(a[p], st.x, st.y);
-            // keep each channel's weight reads next to their use (otherwise all 128 float4 reads are
-            // clustered up front and spill)
-            __builtin_amdgcn_sched_barrier(0);
-        }
         float o[16];
 #pragma unroll
         for (int co = 0; co < 16; ++co) {
-            const float gb = wsm[co][7].z;
-            float gl[4] = {gb, gb, gb, gb};
+            float wv[20];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 g4 = wsm[co][3 + j];
-                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) gl[p] = fmaf(z[p][4 * j + c], gv[c], gl[p]);
+            for (int j = 0; j < 5; ++j) {
+                const float4 q = *reinterpret_cast<const float4 *>(&wsm[co][4 * j]);
+                wv[4 * j] = q.x; wv[4 * j + 1] = q.y; wv[4 * j + 2] = q.z; wv[4 * j + 3] = q.w;
             }
+            float z[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { z[p] = wv[18]; l[p] = wv[19]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float xv = patch[(p >> 1) + k / 3][(p & 1) + k % 3];
+                    z[p] = fmaf(xv, wv[k], z[p]);
+                    l[p] = fmaf(xv, wv[9 + k], l[p]);
+                }
             float sum = 0.f;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) sum += gl[p] * sigmoidf_fast(z[p][co]);
+            for (int p = 0; p < 4; ++p) sum = fmaf(l[p], sigmoidf_fast(z[p]), sum);
             o[co] = 0.25f * sum;
+            // keep each channel's weight reads next to their use (otherwise they are clustered up front and spill)
             __builtin_amdgcn_sched_barrier(0);
         }
         float4 *dst = reinterpret_cast<float4 *>(y + idx * 16);
@@ -847,9 +831,17 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
     {
         Conv0Params p;
         for (int co = 0; co < 16; ++co) {
-            for (int k = 0; k < 9; ++k) p.w[co][k] = w->conv_w[0][co * 9 + k];
-            p.s[co] = s[0][co]; p.t[co] = t[0][co]; p.gb[co] = w->glu_b[0][co];
-            for (int ci = 0; ci < 16; ++ci) p.g[co][ci] = w->glu_w[0][co * 16 + ci];
+            double b2 = w->glu_b[0][co];
+            for (int ci = 0; ci < 16; ++ci) b2 += static_cast<double>(w->glu_w[0][co * 16 + ci]) * t[0][ci];
+            p.t[co] = t[0][co];
+            p.b2[co] = static_cast<float>(b2);
+            for (int k = 0; k < 9; ++k) {
+                p.wz[co][k] = s[0][co] * w->conv_w[0][co * 9 + k];
+                double acc = 0.0;
+                for (int ci = 0; ci < 16; ++ci)
+                    acc += static_cast<double>(w->glu_w[0][co * 16 + ci]) * s[0][ci] * w->conv_w[0][ci * 9 + k];
+                p.wl[co][k] = static_cast<float>(acc);
+            }
         }
         if (hipMalloc(reinterpret_cast<void **>(&m->d_c0), sizeof(p)) != hipSuccess ||
             hipMemcpy(m->d_c0, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess)

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void peak_kernel(float *out, int iters, flo
             if (MODE == 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[i], 0, 0, 0);
             if (MODE == 2) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc4[i], 0, 0, 0);
             if (MODE == 3) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i & 3], br[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+            if (MODE == 4) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[i & 3], br[(i + (i >> 2)) & 3], acc4[i], 0, 0, 0);
         }
     }
     float s = 0.f;
@@ -78,6 +79,7 @@ int main() {
         run<2>("v_mfma_f32_16x16x32_f16", 2.0 * 16 * 16 * 32, d, grid, iters);
     }
     run<3>("32x32x16_f16 random operands", 2.0 * 32 * 32 * 16, d, grid, 200000);
+    run<4>("16x16x32_f16 random operands", 2.0 * 16 * 16 * 32, d, grid, 400000);
     run<1>("v_mfma_f32_32x32x2_f32", 2.0 * 32 * 32 * 2, d, grid, 20000);
     return 0;
 }
