@@ -267,6 +267,36 @@ int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *model, co
                                         void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
+ * BasicRCNN eval-mode forward — replaces BasicRCNN.forward (models.py:45-66)
+ * for the constructor defaults the reference uses (training.py:201:
+ * BasicRCNN(num_classes, 64)): three 3x3 convs with 128 channels,
+ * MaxPool((1,5), stride 1) twice and MaxPool(2,2), ReLU after each pool,
+ * the reshape-not-permute of models.py:59-61, a one-directional GRU with 32
+ * hidden units, ReLU, Linear(32, n_class).  Returns logits.
+ *
+ * Host float32 pointers in the state_dict layouts: conv_w[i] conv{i+1}.weight
+ * ([128,1,3,3], [128,128,3,3], [128,128,3,3]), conv_b[i] conv{i+1}.bias [128],
+ * gru_* gru.{weight_ih,weight_hh,bias_ih,bias_hh}_l0 ([96, 64*(F-8)], [96,32],
+ * [96], [96]), fc_w fc1.weight [n_class, 32], fc_b fc1.bias [n_class].
+ * ------------------------------------------------------------------------ */
+typedef struct sedmi_basic_rcnn sedmi_basic_rcnn;
+
+typedef struct sedmi_basic_rcnn_weights {
+    int n_class;
+    int frequency_dim;                  /* F: feature width, even, >= 10 (64 in the reference) */
+    const float *conv_w[3], *conv_b[3];
+    const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
+    const float *fc_w, *fc_b;
+} sedmi_basic_rcnn_weights;
+
+int sedmi_basic_rcnn_create(sedmi_basic_rcnn **out, const sedmi_basic_rcnn_weights *w);
+int sedmi_basic_rcnn_destroy(sedmi_basic_rcnn *model);
+size_t sedmi_basic_rcnn_workspace_bytes(const sedmi_basic_rcnn *model, int64_t n_clips, int64_t T);
+/* feats [n_clips, T, F] (device) -> logits [n_clips, T/2, n_class] (device). */
+int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *model, const float *feats, int64_t n_clips, int64_t T,
+                                 float *logits, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
  * Thresholding and event decoding.
  * ------------------------------------------------------------------------ */
 

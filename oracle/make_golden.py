@@ -197,6 +197,16 @@ def make_shake(models):
                 out["cnn_small_seq"] = torch.flatten(torch.transpose(x, 1, 2), start_dim=2).numpy()
         print(f"shake {tag} goldens: small", out[f"{tag}_small_logits"].shape, "full", out[f"{tag}_full_logits"].shape,
               "alphas", out[f"{tag}_full_alphas"])
+    # BasicRCNN(num_classes, 64) as training.py:201 builds it; features regenerated by the tests from the seed
+    sd = synth.synth_shake_state_dict(synth.basic_rcnn_state_dict_spec(10, 64), 0)
+    model = models.BasicRCNN(10, 64)
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        out["basic_logits"] = model(torch.from_numpy(synth.synth_shake_feats(4, 3, 501, 64))).numpy()
+        out["basic_small_logits"] = model(torch.from_numpy(synth.synth_shake_feats(5, 2, 37, 64))).numpy()
+    print("basic rcnn goldens:", out["basic_logits"].shape, out["basic_small_logits"].shape,
+          "range", float(out["basic_logits"].min()), float(out["basic_logits"].max()))
     out["small_feats_seed"] = np.array([1, 2, 64]); out["full_feats_seed"] = np.array([2, 1, 1000])
     np.savez_compressed(os.path.join(OUT, "shake_seed0.npz"), **out)
 

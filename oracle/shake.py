@@ -91,3 +91,18 @@ def shake_transformer_forward(sd, feats: torch.Tensor, alphas, layers: int = 6) 
         for i in range(layers):
             x = _encoder_layer(sd, f"encoder.layers.{i}.", x)
         return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def basic_rcnn_forward(sd, feats: torch.Tensor) -> torch.Tensor:
+    """BasicRCNN.forward (models.py:45-66), default hyper-parameters: feats [B, T, F] -> logits [B, T//2, n_cls]."""
+    with torch.no_grad():
+        x = feats.reshape(feats.shape[0], 1, feats.shape[1], feats.shape[2]).to(sd["conv1.weight"].dtype)
+        x = F.relu(F.max_pool2d(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], padding=1), (1, 5), 1))
+        x = F.relu(F.max_pool2d(F.conv2d(x, sd["conv2.weight"], sd["conv2.bias"], padding=1), (1, 5), 1))
+        x = F.relu(F.max_pool2d(F.conv2d(x, sd["conv3.weight"], sd["conv3.bias"], padding=1), (2, 2), 2))
+        b, c, t, w = x.shape
+        x = torch.reshape(x, (b, t, c, w)).flatten(2)            # models.py:59-61: a reinterpretation, not a permute
+        gru = torch.nn.GRU(x.shape[-1], 32, batch_first=True).to(x.dtype)
+        gru.load_state_dict({k[len("gru."):]: v for k, v in sd.items() if k.startswith("gru.")})
+        x, _ = gru(x)
+        return F.linear(F.relu(x), sd["fc1.weight"], sd["fc1.bias"])

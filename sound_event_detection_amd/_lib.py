@@ -68,6 +68,12 @@ class ShakeTransformerWeights(C.Structure):
                 ("layers", ShakeEncoderLayerWeights * SHAKE_MAX_LAYERS), ("fc2_w", _FP), ("fc2_b", _FP)]
 
 
+class BasicRcnnWeights(C.Structure):
+    _FP = C.POINTER(C.c_float)
+    _fields_ = [("n_class", C.c_int), ("frequency_dim", C.c_int), ("conv_w", _FP3), ("conv_b", _FP3),
+                ("gru_w_ih", _FP), ("gru_w_hh", _FP), ("gru_b_ih", _FP), ("gru_b_hh", _FP), ("fc_w", _FP), ("fc_b", _FP)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -103,6 +109,10 @@ SIGNATURES = {
     "sedmi_shake_transformer_destroy": (_I, [_VP]),
     "sedmi_shake_transformer_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
     "sedmi_shake_transformer_forward_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
+    "sedmi_basic_rcnn_create": (_I, [C.POINTER(_VP), C.POINTER(BasicRcnnWeights)]),
+    "sedmi_basic_rcnn_destroy": (_I, [_VP]),
+    "sedmi_basic_rcnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
+    "sedmi_basic_rcnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, _VP, _VP, _SZ, _VP]),
     "sedmi_threshold_i64": (_I, [_VP, _I64, _F, _I, _VP, _VP]),
     "sedmi_decode_workspace_bytes": (_SZ, [_I64, _I]),
     "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,

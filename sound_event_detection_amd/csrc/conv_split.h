@@ -15,6 +15,9 @@
 // sigmoidf_fast from there).
 #pragma once
 
+#ifndef SPLIT_BDIST
+#define SPLIT_BDIST 1
+#endif
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
@@ -78,49 +81,64 @@ __device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int 
     }
 }
 
-// One k-step: A fragments (this lane's rows in the hi / lo LDS planes, pointers already offset by
-// 16*(lane>>5)) are read here; the weights come in registers.
+// One k-step.  The A fragments of m-tile 0 arrive in (ph, pl), read from LDS during the previous
+// step; the other m-tiles' fragments are read here (this lane's rows in the hi / lo planes, pointers
+// already offset by 16*(lane>>5)); the weights come in registers.  Before the last m-tile's MFMAs are
+// issued, m-tile 0 of the NEXT step (LDS offset next_off, < 0 for none) is requested into (ph, pl),
+// so that its LDS latency is covered by those MFMAs rather than paid at the head of the next step.
 template <int MT, int NT>
 __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
-                                           int a_off, const SplitB<NT> &b) {
+                                           int a_off, int next_off, const SplitB<NT> &b, f16x8 &ph, f16x8 &pl) {
     f16x8 vah[MT], val[MT];
+    vah[0] = ph;
+    val[0] = pl;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 1; mt < MT; ++mt) {
         vah[mt] = *reinterpret_cast<const f16x8 *>(ah[mt] + a_off);
         val[mt] = *reinterpret_cast<const f16x8 *>(al[mt] + a_off);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt == MT - 1) {
+            if (MT > 1) __builtin_amdgcn_sched_barrier(0);
+            if (next_off >= 0) {
+                ph = *reinterpret_cast<const f16x8 *>(ah[0] + next_off);
+                pl = *reinterpret_cast<const f16x8 *>(al[0] + next_off);
+            }
+            if (MT > 1) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.l[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
         }
+    }
 }
 
 // acc += A . B over NSTEPS consecutive k-steps.  The weights of step i+1 are requested from L2
-// before the MFMAs of step i issue (their latency is several hundred cycles); the LDS operands are
-// read at the head of their own step and covered by the second wave on the SIMD.
+// before the MFMAs of step i issue (their latency is several hundred cycles).
 // a_off(i) = LDS byte offset of step i relative to ah/al; N = columns of the packed weight matrix
 // (B advances by 4*N uint4 per k-step: 2 planes x N columns x 32 B).
 template <int MT, int NT, int NSTEPS, typename AOff>
 __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
                                            const uint4 *b, int N, AOff a_off) {
     const int BS = N * 4, n2 = N * 2;
-    SplitB<NT> b0, b1;
-    split_load_b<NT>(b0, b, n2);
+    // weights are requested SPLIT_BDIST k-steps ahead of their use, through a ring of register buffers
+    constexpr int D = SPLIT_BDIST, NB = D + 1;
+    SplitB<NT> bb[NB];
 #pragma unroll
-    for (int i = 0; i < NSTEPS; i += 2) {
-        // sched_barrier pins "request the next step's weights, then run this step": left alone, the
+    for (int d = 0; d < D; ++d)
+        if (d < NSTEPS) split_load_b<NT>(bb[d], b + d * BS, n2);
+    f16x8 ph = *reinterpret_cast<const f16x8 *>(ah[0] + a_off(0));
+    f16x8 pl = *reinterpret_cast<const f16x8 *>(al[0] + a_off(0));
+#pragma unroll
+    for (int i = 0; i < NSTEPS; ++i) {
+        // sched_barrier pins "request the later step's weights, then run this step": left alone, the
         // scheduler sinks every load to just above its first use and the wave stalls on each one
-        if (i + 1 < NSTEPS) split_load_b<NT>(b1, b + (i + 1) * BS, n2);
+        if (i + D < NSTEPS) split_load_b<NT>(bb[(i + D) % NB], b + (i + D) * BS, n2);
         __builtin_amdgcn_sched_barrier(0);
-        split_step<MT, NT>(acc, ah, al, a_off(i), b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < NSTEPS) split_load_b<NT>(b0, b + (i + 2) * BS, n2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < NSTEPS) split_step<MT, NT>(acc, ah, al, a_off(i + 1), b1);
+        split_step<MT, NT>(acc, ah, al, a_off(i), i + 1 < NSTEPS ? a_off(i + 1) : -1, bb[i % NB], ph, pl);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -176,10 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     constexpr int ROW_F4 = W * CCH / 4;
     constexpr int STAGE_F4 = (G::TH + 2) * ROW_F4;
     constexpr int NLD = (STAGE_F4 + 255) / 256;
-    for (int c = 0; c < G::NCHUNK; ++c) {
-        // all of this thread's loads are issued before the first one is consumed, so the chunk costs
-        // one memory latency, not NLD of them
-        float4 v[NLD];
+    // all of a thread's loads of a chunk are issued before the first one is consumed, and the loads of
+    // chunk c+1 are issued before the MFMA loop of chunk c: only the first chunk's latency is exposed
+    float4 v[NLD];
+    auto load_chunk = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
@@ -190,6 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             if (i < STAGE_F4 && hr >= 0 && hr < H)
                 v[j] = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(hr) * W + w) * CIN + c * CCH + ch);
         }
+    };
+    load_chunk(0);
+    for (int c = 0; c < G::NCHUNK; ++c) {
+#ifdef SPLIT_NO_CHUNK_PREFETCH
+        if (c) load_chunk(c);
+#endif
         if (c) __syncthreads();                        // every wave is done reading the previous chunk
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -206,6 +230,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             }
         }
         __syncthreads();
+#ifndef SPLIT_NO_CHUNK_PREFETCH
+        if (c + 1 < G::NCHUNK) load_chunk(c + 1);
+#endif
         split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT,
                                        [](int i) {
                                            const int tap = i / G::KS, ks = i % G::KS;

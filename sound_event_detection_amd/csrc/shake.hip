@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void shake_conv1_kernel(const float *__rest
 // ---------------------------------------------------------------------------
 // 3x3 conv as split-f16 implicit GEMM over 8 x 32 position tiles
 // ---------------------------------------------------------------------------
-constexpr int MODE_GLU = 0, MODE_GATE = 1;
+constexpr int MODE_GLU = 0, MODE_GATE = 1, MODE_BIAS = 2;
 constexpr int C2_TR = 8, C2_TC = 32;
 
 template <int CIN, int N, int CCH>
@@ -152,11 +152,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const float *__restrict__ es, const float *__restrict__ et,     // z = acc * es + et per GEMM column
     float alpha,                                                     // MODE_GATE: branch mix
     const float *__restrict__ s2, const float *__restrict__ t2,     // MODE_GATE: second BatchNorm affine
-    float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2]
+    float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2];
+                                      // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine)
     int H, int W, int tiles_x, int tiles_y) {
     using G = Conv2dGeom<CIN, N, CCH>;
     constexpr int NT = G::NT, MT = 2, CO = N / 2;
-    static_assert(MODE == MODE_GLU || CIN == CO, "the gate multiplies the conv input channel by channel");
+    static_assert(MODE != MODE_GATE || CIN == CO, "the gate multiplies the conv input channel by channel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + G::PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,7 +231,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], sc, sh);
     }
-    if constexpr (MODE == MODE_GLU) {
+    if constexpr (MODE == MODE_BIAS) {
+        float *yc = y + clip * static_cast<long>(H) * W * N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ty, tx;
+                tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                const int yy = ty0 + ty, xx = tx0 + tx;
+                if (yy < H && xx < W) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        yc[(static_cast<long>(yy) * W + xx) * N + col32 + 32 * nt] = acc[mt][nt][r];
+                }
+            }
+    } else if constexpr (MODE == MODE_GLU) {
         float *yc = y + clip * static_cast<long>(H) * W * CO;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -642,6 +658,144 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *x, const float
     }
 }
 
+// ---------------------------------------------------------------------------
+// BasicRCNN (models.py:7-66) pieces that are not a 3x3 split-f16 conv
+// ---------------------------------------------------------------------------
+constexpr int BR_C = 128;            // conv channels (models.py:14)
+constexpr int BR_H = 32;             // GRU hidden size (models.py:9)
+
+// conv1: 3x3, 1 -> 128 channels, + bias; x [clip][T][F] -> y [clip][T][F][128].  One thread = one
+// position x 8 channels (K = 9 is too thin for the matrix cores).
+__global__ __launch_bounds__(256) void basic_conv1_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y,
+                                                          long n_clips, int T, int F) {
+    __shared__ float wsm[BR_C][10];
+    for (int i = threadIdx.x; i < BR_C * 10; i += 256) {
+        const int c = i / 10, k = i - c * 10;
+        wsm[c][k] = k < 9 ? w[c * 9 + k] : bias[c];
+    }
+    __syncthreads();
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    const long total = n_clips * T * F * (BR_C / 8);
+    if (idx >= total) return;
+    const int cg = static_cast<int>(idx % (BR_C / 8));
+    const long pos = idx / (BR_C / 8);
+    const int f = static_cast<int>(pos % F);
+    const long rest = pos / F;
+    const int t = static_cast<int>(rest % T);
+    const float *xb = x + (rest / T) * static_cast<long>(T) * F;
+    float patch[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int tt = t - 1 + k / 3, ff = f - 1 + k % 3;
+        patch[k] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? xb[static_cast<long>(tt) * F + ff] : 0.f;
+    }
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float *wr = wsm[cg * 8 + c];
+        float a = wr[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a = fmaf(patch[k], wr[k], a);
+        o[c] = a;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(y + pos * BR_C + cg * 8);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// MaxPool2d((1, 5), stride 1) + ReLU (models.py:30,49-50): [clip*T][W][128] -> [clip*T][W-4][128]
+__global__ __launch_bounds__(256) void maxpool_w5_relu_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              long n_rows, int W) {
+    const int Wo = W - 4;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n_rows * Wo * (BR_C / 4)) return;
+    const int c4 = static_cast<int>(idx % (BR_C / 4));
+    const long p = idx / (BR_C / 4);
+    const int wo = static_cast<int>(p % Wo);
+    const long row = p / Wo;
+    const float4 *src = reinterpret_cast<const float4 *>(x + (row * W + wo) * BR_C) + c4;
+    float4 m = src[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        const float4 v = src[k * (BR_C / 4)];
+        m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+    }
+    reinterpret_cast<float4 *>(y + (row * Wo + wo) * BR_C)[c4] =
+        make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
+}
+
+// MaxPool2d(2, 2) + ReLU (models.py:34,55-56), written in the reference's memory order
+// [clip][chan][T/2][W/2]: the model then re-reads those bytes as [clip][T/2][chan * W/2]
+// (torch.reshape at models.py:59-61 is a reinterpretation, not a permute).
+__global__ __launch_bounds__(256) void maxpool2x2_relu_nchw_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                   long n_clips, int T, int W) {
+    const int T2 = T / 2, W2 = W / 2;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n_clips * T2 * W2 * BR_C) return;
+    const int c = static_cast<int>(idx % BR_C);        // threads run along channels: coalesced reads
+    const long p = idx / BR_C;
+    const int w2 = static_cast<int>(p % W2);
+    const long q = p / W2;
+    const int t2 = static_cast<int>(q % T2);
+    const long b = q / T2;
+    const float *src = x + ((b * T + 2 * t2) * static_cast<long>(W) + 2 * w2) * BR_C + c;
+    const float m = fmaxf(fmaxf(src[0], src[BR_C]), fmaxf(src[static_cast<long>(W) * BR_C], src[(static_cast<long>(W) + 1) * BR_C]));
+    y[((b * BR_C + c) * static_cast<long>(T2) + t2) * W2 + w2] = fmaxf(m, 0.f);
+}
+
+// GRU(K, 32) recurrence, one direction, + ReLU + Linear(32, n_cls) (models.py:62-65): one wave per
+// clip.  gi [clip*T2][128] holds W_ih x + b_ih (+ b_hh for r, z) in columns 0..95.
+__global__ __launch_bounds__(64) void basic_gru_head_kernel(const float *__restrict__ gi, const float *__restrict__ whh,
+                                                            const float *__restrict__ bhn, const float *__restrict__ fw,
+                                                            const float *__restrict__ fb, float *__restrict__ logits,
+                                                            int T2, int n_cls) {
+    __shared__ float hs[BR_H], hrelu[BR_H], gh[3 * BR_H];
+    const int lane = threadIdx.x;
+    const long b = blockIdx.x;
+    // lane l computes the recurrent pre-activations of gate columns l and l + 64 (96 in all)
+    float w0[BR_H], w1[BR_H];
+#pragma unroll
+    for (int k = 0; k < BR_H; ++k) {
+        w0[k] = whh[lane * BR_H + k];
+        w1[k] = lane < 32 ? whh[(lane + 64) * BR_H + k] : 0.f;
+    }
+    const float b_hn = lane < BR_H ? bhn[lane] : 0.f;
+    if (lane < BR_H) hs[lane] = 0.f;
+    float h = 0.f;
+    __syncthreads();
+    for (int t = 0; t < T2; ++t) {
+        const float *g = gi + (b * T2 + t) * 128;
+        const float gr = lane < BR_H ? g[lane] : 0.f, gz = lane < BR_H ? g[BR_H + lane] : 0.f,
+                    gn = lane < BR_H ? g[2 * BR_H + lane] : 0.f;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < BR_H; ++k) {
+            const float hv = hs[k];
+            a0 = fmaf(hv, w0[k], a0);
+            a1 = fmaf(hv, w1[k], a1);
+        }
+        gh[lane] = a0;
+        if (lane < 32) gh[lane + 64] = a1;
+        __syncthreads();
+        if (lane < BR_H) {
+            const float r = 1.0f / (1.0f + __expf(-(gr + gh[lane])));
+            const float z = 1.0f / (1.0f + __expf(-(gz + gh[BR_H + lane])));
+            const float n = tanhf(fmaf(r, gh[2 * BR_H + lane] + b_hn, gn));
+            h = fmaf(z, h - n, n);
+            hs[lane] = h;
+            hrelu[lane] = fmaxf(h, 0.f);
+        }
+        __syncthreads();
+        for (int c = lane; c < n_cls; c += 64) {
+            float a = fb[c];
+#pragma unroll
+            for (int k = 0; k < BR_H; ++k) a = fmaf(hrelu[k], fw[c * BR_H + k], a);
+            logits[(b * T2 + t) * n_cls + c] = a;
+        }
+    }
+}
+
 constexpr int kShakeChunk = 16;     // clips per pass through the conv blocks (u1 is 49 MB per clip)
 constexpr int kMaxEncoderLayers = SEDMI_SHAKE_MAX_LAYERS;
 
@@ -687,6 +841,15 @@ struct sedmi_shake_transformer {
     LinearDev fc1;
     EncoderLayerDev layers[kMaxEncoderLayers];
     float *d_fw = nullptr, *d_fb = nullptr;
+};
+
+struct sedmi_basic_rcnn {
+    int n_class = 0, F = 0, K = 0;        // K = GRU input width = 128 * (F - 8) / 2
+    float *d_w1 = nullptr, *d_b1 = nullptr;
+    uint16_t *d_wc[2] = {nullptr, nullptr};               // conv2, conv3 packed split weights
+    float *d_es[2] = {nullptr, nullptr}, *d_et[2] = {nullptr, nullptr};
+    LinearDev wih;                                        // 96 gate columns padded to 128
+    float *d_whh = nullptr, *d_bhn = nullptr, *d_fw = nullptr, *d_fb = nullptr;
 };
 
 namespace {
@@ -740,7 +903,8 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     const double pos = static_cast<double>(n) * H * W;
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
-                             pos * 4.0 * (CIN + (MODE == MODE_GLU ? N / 2.0 : CIN + N / 2.0 / (PH * PW))));
+                             pos * 4.0 * (CIN + (MODE == MODE_BIAS ? N : MODE == MODE_GLU ? N / 2.0
+                                                                                        : CIN + N / 2.0 / (PH * PW))));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n * tiles_x * tiles_y)), dim3(256), G::LDS_BYTES, s, x,
                        reinterpret_cast<const uint4 *>(wp), es, et, alpha, s2, t2, y, H, W, tiles_x, tiles_y);
     SEDMI_CHECK_LAUNCH();
@@ -1132,6 +1296,144 @@ int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const 
     sedmi::ProfileScope prof("shake_tf_head", s, 2.0 * rows * 1024.0 * m->n_class, 4.0 * rows * (1024.0 + m->n_class));
     hipLaunchKernelGGL((ln_head_kernel<1024, false>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
                        sc.x, nullptr, nullptr, m->d_fw, m->d_fb, logits, rows, m->n_class);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BasicRCNN
+// ---------------------------------------------------------------------------
+static constexpr int kBasicChunk = 32;      // clips per pass through the conv stack (16 MB of activations per clip)
+
+struct BasicScratch {
+    float *a, *b, *seq, *gi;
+    size_t bytes;
+};
+
+static BasicScratch carve_basic(void *ws, const sedmi_basic_rcnn *m, long n, long T) {
+    BasicScratch sc{};
+    size_t off = 0;
+    auto take = [&](size_t n_floats) {
+        float *p = reinterpret_cast<float *>(static_cast<char *>(ws) + off);
+        off += sedmi::align_up(n_floats * sizeof(float), 256);
+        return p;
+    };
+    const long ch = std::min<long>(n, kBasicChunk), T2 = T / 2;
+    sc.a = take(static_cast<size_t>(ch) * T * m->F * BR_C);
+    sc.b = take(static_cast<size_t>(ch) * T * m->F * BR_C);
+    sc.seq = take(static_cast<size_t>(n) * T2 * m->K);
+    sc.gi = take(static_cast<size_t>(n) * T2 * 128);
+    sc.bytes = off;
+    return sc;
+}
+
+int sedmi_basic_rcnn_create(sedmi_basic_rcnn **out, const sedmi_basic_rcnn_weights *w) {
+    SEDMI_REQUIRE(out && w, "null argument");
+    *out = nullptr;
+    SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
+    SEDMI_REQUIRE(w->frequency_dim >= 10 && w->frequency_dim % 2 == 0 && w->frequency_dim <= 4096,
+                  "frequency_dim %d: need an even value >= 10", w->frequency_dim);
+    for (int i = 0; i < 3; ++i) SEDMI_REQUIRE(w->conv_w[i] && w->conv_b[i], "null conv weight pointer");
+    SEDMI_REQUIRE(w->gru_w_ih && w->gru_w_hh && w->gru_b_ih && w->gru_b_hh && w->fc_w && w->fc_b, "null weight pointer");
+    auto *m = new sedmi_basic_rcnn();
+    m->n_class = w->n_class;
+    m->F = w->frequency_dim;
+    m->K = BR_C * ((m->F - 8) / 2);
+    int rc;
+    auto fail = [&](int code) { sedmi_basic_rcnn_destroy(m); return code; };
+    if ((rc = upload_floats(&m->d_w1, w->conv_w[0], BR_C * 9)) || (rc = upload_floats(&m->d_b1, w->conv_b[0], BR_C)))
+        return fail(rc);
+    for (int l = 0; l < 2; ++l) {
+        const float *src = w->conv_w[l + 1];
+        const int S = split_scale_exp(src, static_cast<size_t>(BR_C) * BR_C * 9);
+        auto packed = pack_split(9 * BR_C / 16, BR_C, S, [&](int kidx, int k16, int n) {
+            const int ks = kidx % 2, tap = (kidx / 2) % 9, ch = (kidx / 18) * 32 + ks * 16 + k16;   // chunk / tap / k
+            return src[(static_cast<size_t>(n) * BR_C + ch) * 9 + tap];
+        });
+        std::vector<float> es(BR_C, std::ldexp(1.0f, -S));
+        if ((rc = sedmi::upload(&m->d_wc[l], packed)) || (rc = sedmi::upload(&m->d_es[l], es)) ||
+            (rc = upload_floats(&m->d_et[l], w->conv_b[l + 1], BR_C)))
+            return fail(rc);
+    }
+    {
+        std::vector<float> wpad(static_cast<size_t>(128) * m->K, 0.f), bi(128, 0.f);
+        std::memcpy(wpad.data(), w->gru_w_ih, sizeof(float) * 3 * BR_H * m->K);
+        for (int n = 0; n < 3 * BR_H; ++n) bi[n] = w->gru_b_ih[n] + (n < 2 * BR_H ? w->gru_b_hh[n] : 0.f);
+        if ((rc = make_linear(m->wih, wpad.data(), bi.data(), 128, m->K, [](int k) { return k; }))) return fail(rc);
+    }
+    if ((rc = upload_floats(&m->d_whh, w->gru_w_hh, 3 * BR_H * BR_H)) ||
+        (rc = upload_floats(&m->d_bhn, w->gru_b_hh + 2 * BR_H, BR_H)) ||
+        (rc = upload_floats(&m->d_fw, w->fc_w, static_cast<size_t>(w->n_class) * BR_H)) ||
+        (rc = upload_floats(&m->d_fb, w->fc_b, w->n_class)))
+        return fail(rc);
+    *out = m;
+    return SEDMI_OK;
+}
+
+int sedmi_basic_rcnn_destroy(sedmi_basic_rcnn *m) {
+    if (!m) return SEDMI_OK;
+    (void)hipFree(m->d_w1); (void)hipFree(m->d_b1);
+    for (int l = 0; l < 2; ++l) { (void)hipFree(m->d_wc[l]); (void)hipFree(m->d_es[l]); (void)hipFree(m->d_et[l]); }
+    free_linear(m->wih);
+    (void)hipFree(m->d_whh); (void)hipFree(m->d_bhn); (void)hipFree(m->d_fw); (void)hipFree(m->d_fb);
+    delete m;
+    return SEDMI_OK;
+}
+
+size_t sedmi_basic_rcnn_workspace_bytes(const sedmi_basic_rcnn *m, int64_t n_clips, int64_t T) {
+    if (!m || n_clips <= 0 || T < 2) return 0;
+    return carve_basic(nullptr, m, n_clips, T).bytes;
+}
+
+int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, int64_t n, int64_t T, float *logits,
+                                 void *ws, size_t ws_bytes, void *stream) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(n >= 0 && T >= 0 && T < (1 << 24) && n < (1LL << 31), "bad shape");
+    if (n == 0 || T < 2) return SEDMI_OK;
+    SEDMI_REQUIRE(feats && logits && ws, "null pointer");
+    BasicScratch sc = carve_basic(ws, m, n, T);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int F = m->F, Ti = static_cast<int>(T), T2 = Ti / 2;
+    int rc;
+    auto blocks = [](long total) { return dim3(static_cast<unsigned>(sedmi::ceil_div(total, 256))); };
+    for (long c0 = 0; c0 < n; c0 += kBasicChunk) {
+        const long nc = std::min<long>(kBasicChunk, n - c0);
+        const long rows = nc * Ti;
+        {
+            sedmi::ProfileScope prof("basic_conv1", s, 2.0 * 9 * BR_C * rows * F, 4.0 * rows * F * (1.0 + BR_C));
+            hipLaunchKernelGGL(basic_conv1_kernel, blocks(rows * F * (BR_C / 8)), dim3(256), 0, s,
+                               feats + c0 * static_cast<long>(Ti) * F, m->d_w1, m->d_b1, sc.a, nc, Ti, F);
+            SEDMI_CHECK_LAUNCH();
+        }
+        {
+            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (2.0 * F - 4));
+            hipLaunchKernelGGL(maxpool_w5_relu_kernel, blocks(rows * (F - 4) * (BR_C / 4)), dim3(256), 0, s, sc.a, sc.b, rows, F);
+            SEDMI_CHECK_LAUNCH();
+        }
+        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
+                                                              nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 4, s))) return rc;
+        {
+            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (2.0 * F - 12));
+            hipLaunchKernelGGL(maxpool_w5_relu_kernel, blocks(rows * (F - 8) * (BR_C / 4)), dim3(256), 0, s, sc.a, sc.b, rows,
+                               F - 4);
+            SEDMI_CHECK_LAUNCH();
+        }
+        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1], 0.f,
+                                                              nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 8, s))) return rc;
+        {
+            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (F - 8) * 1.25);
+            hipLaunchKernelGGL(maxpool2x2_relu_nchw_kernel, blocks(nc * T2 * ((F - 8) / 2) * BR_C), dim3(256), 0, s, sc.a,
+                               sc.seq + c0 * static_cast<long>(T2) * m->K, nc, Ti, F - 8);
+            SEDMI_CHECK_LAUNCH();
+        }
+    }
+    const long grows = n * T2;
+    if ((rc = launch_linear("basic_gru_input_proj", m->wih, sc.seq, sc.gi, grows, false, s))) return rc;
+    sedmi::ProfileScope prof("basic_gru_head", s, 2.0 * grows * (3.0 * BR_H * BR_H + BR_H * m->n_class),
+                             4.0 * grows * (128.0 + m->n_class));
+    hipLaunchKernelGGL(basic_gru_head_kernel, dim3(static_cast<unsigned>(n)), dim3(64), 0, s, sc.gi, m->d_whh, m->d_bhn,
+                       m->d_fw, m->d_fb, logits, T2, m->n_class);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

@@ -1,4 +1,4 @@
-"""ShakeRCNN and ShakeTransformer on MI355X behind the reference's interface.
+"""BasicRCNN, ShakeRCNN and ShakeTransformer on MI355X behind the reference's interface.
 
 Mirrors /root/reference/models.py: ``ShakeRCNN(num_classes, dropout=0)``
 (:105-121), ``forward(x) -> logits [B, T/4, num_classes]`` (:124-142),
@@ -27,6 +27,79 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+
+
+class BasicRCNN(nn.Module):
+    """models.py:7-66 with the constructor defaults (the only form training.py:201 builds):
+    ``BasicRCNN(num_classes, frequency_dim)``; ``forward(x [B, T, frequency_dim]) -> logits
+    [B, T // 2, num_classes]``; state_dict keys conv{1,2,3}.*, gru.*_l0, fc1.*."""
+
+    def __init__(self, num_classes, frequency_dim, conv_kernels=None, conv_channels=None, maxpool_kernels=None,
+                 gru_hidden_channels=32, bidirectional_gru=False, dropout=0.):
+        super().__init__()
+        if (conv_kernels not in (None, [3, 3, 3]) or conv_channels not in (None, [128, 128, 128])
+                or maxpool_kernels not in (None, [5, 5, 2]) or gru_hidden_channels != 32 or bidirectional_gru):
+            raise NotImplementedError("the HIP path implements BasicRCNN's default hyper-parameters only "
+                                      "(3x3 convs, 128 channels, max-pools 5/5/2, GRU(32), one direction)")
+        self.num_classes = int(num_classes)
+        self.frequency_dim = int(frequency_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.conv1 = nn.Conv2d(1, 128, 3, padding=1)
+        self.conv2 = nn.Conv2d(128, 128, 3, padding=1)
+        self.conv3 = nn.Conv2d(128, 128, 3, padding=1)
+        self.gru_input_dim = int(((self.frequency_dim - 8) // 2) * 128)
+        self.gru = nn.GRU(self.gru_input_dim, 32, batch_first=True, bidirectional=False)
+        self.fc1 = nn.Linear(32, num_classes)
+        self._handle = self._handle_sig = self._handle_fin = None
+
+    def _get_handle(self, device):
+        ts = list(self.parameters()) + list(self.buffers())
+        sig = (device.index, tuple((t.data_ptr(), t._version) for t in ts))
+        if self._handle is not None and self._handle_sig == sig:
+            return self._handle
+        if self._handle_fin is not None:
+            self._handle_fin()
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+        fp = C.POINTER(C.c_float)
+
+        def p(key):
+            return C.cast(C.c_void_p(sd[key].data_ptr()), fp)
+
+        w = _lib.BasicRcnnWeights()
+        w.n_class, w.frequency_dim = self.num_classes, self.frequency_dim
+        for i in range(3):
+            w.conv_w[i], w.conv_b[i] = p(f"conv{i + 1}.weight"), p(f"conv{i + 1}.bias")
+        w.gru_w_ih, w.gru_w_hh = p("gru.weight_ih_l0"), p("gru.weight_hh_l0")
+        w.gru_b_ih, w.gru_b_hh = p("gru.bias_ih_l0"), p("gru.bias_hh_l0")
+        w.fc_w, w.fc_b = p("fc1.weight"), p("fc1.bias")
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().sedmi_basic_rcnn_create(C.byref(handle), C.byref(w)), "sedmi_basic_rcnn_create")
+        self._handle, self._handle_sig = handle, sig
+        self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_basic_rcnn_destroy, handle)
+        return handle
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("inference-only model: call model.eval() first")
+        if not x.is_cuda:
+            raise _lib.SedmiError("forward needs a CUDA (ROCm) tensor: the model runs in HIP kernels only")
+        if x.dim() != 3 or x.shape[2] != self.frequency_dim:
+            raise ValueError(f"expected features [batch, frames, {self.frequency_dim}], got {tuple(x.shape)}")
+        x = x.to(torch.float32).contiguous()                     # x.float() at models.py:48
+        handle = self._get_handle(x.device)
+        B, T, _ = x.shape
+        lib = _lib.lib()
+        logits = torch.empty((B, T // 2, self.num_classes), dtype=torch.float32, device=x.device)
+        if B == 0 or T < 2:
+            return logits
+        ws_bytes = lib.sedmi_basic_rcnn_workspace_bytes(handle, B, T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sedmi_basic_rcnn_forward_f32(handle, _lib.ptr(x), B, T, _lib.ptr(logits), _lib.ptr(ws),
+                                                        ws_bytes, _lib.stream_ptr(x.device)),
+                       "sedmi_basic_rcnn_forward_f32")
+        return logits
 
 
 class ShakeShakeBlock(nn.Module):

@@ -213,3 +213,14 @@ def synth_shake_feats(seed: int, n_clips: int, n_frames: int = 1000, n_bins: int
     x = rng.standard_normal((n_clips, n_frames, n_bins), dtype=np.float32)
     drift = np.sin(np.arange(n_frames, dtype=np.float32)[:, None] * 0.02 + np.arange(n_bins, dtype=np.float32)[None] * 0.05)
     return (x + 0.5 * drift).astype(np.float32)
+
+
+def basic_rcnn_state_dict_spec(num_classes: int = 10, frequency_dim: int = 64):
+    """Ordered (key, shape) list of BasicRCNN's state_dict (models.py:29-43, default hyper-parameters)."""
+    k = ((frequency_dim - 8) // 2) * 128
+    return [("conv1.weight", (128, 1, 3, 3)), ("conv1.bias", (128,)),
+            ("conv2.weight", (128, 128, 3, 3)), ("conv2.bias", (128,)),
+            ("conv3.weight", (128, 128, 3, 3)), ("conv3.bias", (128,)),
+            ("gru.weight_ih_l0", (96, k)), ("gru.weight_hh_l0", (96, 32)),
+            ("gru.bias_ih_l0", (96,)), ("gru.bias_hh_l0", (96,)),
+            ("fc1.weight", (num_classes, 32)), ("fc1.bias", (num_classes,))]

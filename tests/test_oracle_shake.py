@@ -49,3 +49,13 @@ def test_alpha_changes_output(gold, small):
     a = shake.shake_cnn(sd, small, [0.1, 0.1, 0.1])
     b = shake.shake_cnn(sd, small, [0.9, 0.9, 0.9])
     assert float((a - b).abs().max()) > 1e-3
+
+
+def test_basic_rcnn_matches_reference(gold):
+    sd = synth.synth_shake_state_dict(synth.basic_rcnn_state_dict_spec(10, 64), 0)
+    got = shake.basic_rcnn_forward(sd, torch.from_numpy(synth.synth_shake_feats(5, 2, 37, 64))).numpy()
+    np.testing.assert_allclose(got, gold["basic_small_logits"], rtol=0, atol=2e-5)
+    # reshape-not-permute (models.py:59-61): a permute would give a different answer
+    sd64 = {k: v.double() for k, v in sd.items()}
+    got64 = shake.basic_rcnn_forward(sd64, torch.from_numpy(synth.synth_shake_feats(5, 2, 37, 64)).double()).numpy()
+    assert np.abs(got64 - gold["basic_small_logits"]).max() < 1e-4
