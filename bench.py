@@ -187,7 +187,11 @@ def main():
                         avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
                         flop_per_launch=dom["flops"] / dom["launches"],
                         mfma_per_product=3 if split else 1,
-                        mfma_issue_frac=(3 if split else 1) * dom["tflops"] / peak)
+                        mfma_issue_frac=(3 if split else 1) * dom["tflops"] / peak,
+                        # tools/mfma_peak on this pool: a register-resident v_mfma_f32_32x32x16_f16 loop holds
+                        # 2.48 PFLOP/s on constant operands but 1.63-1.72 on random ones (the chip lowers its
+                        # clock under load), which caps split-f16 work at ~0.55-0.57 PFLOP/s algorithmic
+                        peak_sustained_random_operands=1700.0 if split else None)
         else:
             roof = dict(kernel=dom["name"], bound="hbm", achieved=dom["gbps"], peak=PEAK_HBM_GBPS, unit="GB/s",
                         frac=dom["gbps"] / PEAK_HBM_GBPS, traffic=None, avg_launch_ms=dom["avg_ms"],
@@ -196,7 +200,11 @@ def main():
         # cannot run inside this process); null if that kernel has not been profiled
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                roof["traffic"] = json.load(f).get(dom["name"])
+                rec = json.load(f).get(dom["name"])
+            if rec:
+                roof["traffic"] = rec["hbm_bytes_per_launch"]          # bytes per launch, PMC-measured
+                roof["traffic_detail"] = {k: rec[k] for k in ("fetch_size_kib_raw", "write_size_kib", "note")}
+                roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
         except (OSError, ValueError):
             pass
         cpu = None
