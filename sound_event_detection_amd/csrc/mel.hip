@@ -12,17 +12,19 @@
 //     R1 x 4 x 16 Cooley-Tukey split (R1 = NC/64) whose butterflies live in
 //     registers; the three stages exchange data through a per-wave LDS
 //     scratch (three transposes), then each lane untangles bin pairs
-//     (k, NC-k) of the real spectrum and writes |X|^2 into a block-shared
-//     power tile P[bin][frame];
-//   * a workgroup owns FPB consecutive frames of one clip; after a barrier
-//     it applies the filterbank as a sparse contraction (every filter is a
-//     short contiguous run of bins: 2020 non-zeros of 131200 for 128 mels at
-//     n_fft 2048), lanes = (filter, frame) so that all lanes of a wave run
-//     the same trip count and the weights are LDS broadcasts;
-//   * output is written mel-major [clip][mel][frame], FPB frames (64 B) at a
-//     time; the reference's "reshape" of that array is a free reinterpretation.
-//   * workgroups are persistent over (clip, tile) work items so that the
-//     per-lane twiddles and window taps are loaded once and stay in VGPRs.
+//     (k, NC-k) of the real spectrum and leaves |X|^2 in the same scratch;
+//   * the wave then applies the filterbank itself as a sparse contraction,
+//     lane = filter (every filter is a short contiguous run of bins: 2020
+//     non-zeros of 131200 for 128 mels at n_fft 2048), eight bins in flight
+//     per lane, weights in LDS with run starts skewed across bank groups;
+//   * a wave never waits for another wave: no workgroup barrier in the frame
+//     loop, LDS = 8.7 KB of scratch per wave + the weights, which leaves room
+//     for three waves per SIMD to cover the LDS round trips;
+//   * output is mel-major [clip][mel][frame]; neighbouring waves work on
+//     neighbouring frames, so the 4-byte writes of a line merge in L2.  The
+//     reference's "reshape" of that array is a free reinterpretation;
+//   * waves are persistent over frames so that the per-lane twiddles and
+//     window taps are loaded once and stay in VGPRs.
 #include "common.h"
 
 #include <cmath>
@@ -41,10 +43,10 @@ struct MelArgs {
     int zlo, zhi;            // complex indices with a non-zero window tap: [zlo, zhi)
     int n_mels;
     const int *mel_start;    // first bin of each filter
-    const int *mel_len;      // number of bins
-    const int *mel_ptr;      // offset into mel_w
-    const float *mel_w;
-    int nnz;
+    const int *mel_len;      // number of bins, rounded up to a multiple of 8
+    const int *mel_ptr;      // offset into mel_w (a multiple of 4, skewed against LDS bank conflicts)
+    const float *mel_w;      // every filter's run of weights, zero-padded to its rounded length
+    int nnz;                 // floats in mel_w
     float *out;
     int flags;
     const float *mean;
@@ -139,21 +141,25 @@ struct MelGeom {
 // ROW0 / NROW: the first-stage rows n1 in [ROW0, ROW0 + NROW) are the only ones whose 64 complex
 // points can carry a non-zero window tap (win 640 centred in n_fft 2048: rows 5..10 of 16); the
 // others are compile-time zeros, are never loaded, and their butterflies fold away.
-template <int R1, int WAVES, int FPB, int ROW0, int NROW>
-__global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
+//
+// A wave is self-contained: it transforms a frame, leaves the power spectrum in its own LDS scratch
+// and applies the filterbank to it (lane = filter), so there is no workgroup barrier in the frame
+// loop and the LDS footprint is the scratch alone (three 4-wave workgroups per CU at n_fft 2048:
+// three waves per SIMD to cover the LDS round trips of the transposes).
+template <int R1, int WAVES, int ROW0, int NROW>
+__global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(const MelArgs a) {
     using G = MelGeom<R1>;
     constexpr int NC = G::NC;
-    constexpr int PS = FPB + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *scr_all = reinterpret_cast<float2 *>(smem);
-    float *P = reinterpret_cast<float *>(smem + sizeof(float2) * G::SCR * WAVES);
-    float *melw = P + (NC + 1) * PS;
-    int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     float2 *scr = scr_all + wave * G::SCR;
+    float *melw = reinterpret_cast<float *>(smem + sizeof(float2) * G::SCR * WAVES);
+    int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));
+    float *pw = reinterpret_cast<float *>(scr);        // power spectrum [NC + 1], aliases the scratch
 
     // ---- one-time per-workgroup / per-lane constants ------------------------
     for (int i = tid; i < a.nnz; i += WAVES * 64) melw[i] = a.mel_w[i];
@@ -186,9 +192,14 @@ __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
         t2r[p] = t.x;
         t2i[p] = t.y;
     }
-    float t3r[G::NPAIR], t3i[G::NPAIR];   // untangle twiddles W_2NC^k, k = lane + 64 j
+    // untangle twiddles W_2NC^k, k = lane + 64 j.  For R1 <= 16 only j = 0 is kept in registers: the
+    // factor W_2NC^(64 j) = exp(-2 pi i j / (2 R1)) is a compile-time constant, and the 16 registers
+    // this frees are what lets three waves share a SIMD.
+    constexpr bool kT3Const = R1 <= 16;
+    constexpr int NT3 = kT3Const ? 1 : G::NPAIR;
+    float t3r[NT3], t3i[NT3];
 #pragma unroll
-    for (int j = 0; j < G::NPAIR; ++j) {
+    for (int j = 0; j < NT3; ++j) {
         const int k = lane + 64 * j;
         const float2 t = a.tw_post[k <= NC / 2 ? k : 0];
         t3r[j] = t.x;
@@ -196,12 +207,16 @@ __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
     }
     __syncthreads();
 
+    // frames are dealt to waves round robin over the whole launch: neighbouring waves work on
+    // neighbouring frames of a clip at about the same time, so the overlapping input samples and
+    // the partially written output lines meet in L2
+    const long total_frames = a.total_tiles;           // clips * T
+    const long stride = static_cast<long>(gridDim.x) * WAVES;
     // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use
-    constexpr int UPT = FPB / WAVES;                   // frames per wave per tile
-    auto load_raw = [&](long tile, int u, float (&r0)[NROW], float (&r1)[NROW]) {
-        const long clip = tile / a.tiles_per_clip;
-        const int t = static_cast<int>(tile - clip * a.tiles_per_clip) * FPB + wave + WAVES * u;
-        const bool live = tile < a.total_tiles && t < a.T;
+    auto load_raw = [&](long f, float (&r0)[NROW], float (&r1)[NROW]) {
+        const bool live = f < total_frames;
+        const long clip = live ? f / a.T : 0;
+        const int t = static_cast<int>(f - clip * a.T);
         const float *yc = a.y + clip * a.n_samples;
         const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
 #pragma unroll
@@ -212,146 +227,165 @@ __global__ __launch_bounds__(WAVES * 64) void mel_kernel(const MelArgs a) {
         }
     };
     float raw0[NROW], raw1[NROW];
-    load_raw(blockIdx.x, 0, raw0, raw1);
+    long f = static_cast<long>(blockIdx.x) * WAVES + wave;
+    load_raw(f, raw0, raw1);
 
-    for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const long clip = tile / a.tiles_per_clip;
-        const int f0 = static_cast<int>(tile - clip * a.tiles_per_clip) * FPB;
-
+    for (; f < total_frames; f += stride) {
+        const long clip = f / a.T;
+        const int t = static_cast<int>(f - clip * a.T);
+        // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
+        float re[R1], im[R1];
 #pragma unroll
-        for (int u = 0; u < UPT; ++u) {
-            const int fi = wave + WAVES * u;
-            const int t = f0 + fi;
-            // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
-            float re[R1], im[R1];
-#pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) {
-                re[n1] = 0.f;
-                im[n1] = 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < NROW; ++i) {
-                re[ROW0 + i] = raw0[i] * w0[i];
-                im[ROW0 + i] = raw1[i] * w1[i];
-            }
-            // request the next frame of this wave (next u, or the first frame of the next tile)
-            if (u + 1 < UPT) load_raw(tile, u + 1, raw0, raw1);
-            else load_raw(tile + gridDim.x, 0, raw0, raw1);
-            if (t >= a.T) continue;                    // wave-uniform: frame past the end of the clip
-            dif<R1>(re, im);
-#pragma unroll
-            for (int p = 0; p < R1; ++p) {             // twiddle, then transpose A: [k1][n2]
-                const float xr = re[p] * t1r[p] - im[p] * t1i[p];
-                const float xi = re[p] * t1i[p] + im[p] * t1r[p];
-                scr[bitrev<R1>(p) * G::STRIDE_A + lane] = make_float2(xr, xi);
-            }
-            wave_lds_fence();
-            // ---- stage 2a: radix-4 over p (n2 = 16 p + q), lane = (q, g) --------
-            float br[R1 / 4][4], bi[R1 / 4][4];
-#pragma unroll
-            for (int i = 0; i < R1 / 4; ++i) {
-                const int k1 = g * (R1 / 4) + i;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float2 v = scr[k1 * G::STRIDE_A + 16 * p + q];
-                    br[i][p] = v.x;
-                    bi[i][p] = v.y;
-                }
-            }
-            wave_lds_fence();                          // all reads before scratch is reused
-#pragma unroll
-            for (int i = 0; i < R1 / 4; ++i) {
-                const int k1 = g * (R1 / 4) + i;
-                dif<4>(br[i], bi[i]);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {          // twiddle W_64^(q r), transpose B: [q][r*R1 + k1]
-                    const int r = bitrev<4>(p);
-                    const float xr = br[i][p] * t2r[p] - bi[i][p] * t2i[p];
-                    const float xi = br[i][p] * t2i[p] + bi[i][p] * t2r[p];
-                    scr[q * G::STRIDE_B + r * R1 + k1] = make_float2(xr, xi);
-                }
-            }
-            wave_lds_fence();
-            // ---- stage 2b: radix-16 over q, one butterfly per (r, k1) ----------
-            constexpr int NB = (4 * R1 + 63) / 64;
-            float cr[NB][16], ci[NB][16];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int idx = lane + 64 * u;
-                if (idx < 4 * R1) {
-#pragma unroll
-                    for (int qq = 0; qq < 16; ++qq) {
-                        const float2 v = scr[qq * G::STRIDE_B + idx];
-                        cr[u][qq] = v.x;
-                        ci[u][qq] = v.y;
-                    }
-                }
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int idx = lane + 64 * u;
-                if (idx < 4 * R1) {
-                    dif<16>(cr[u], ci[u]);
-                    const int r = idx / R1, k1 = idx % R1;
-#pragma unroll
-                    for (int p = 0; p < 16; ++p) {     // natural order Z[k], k = k1 + R1 (r + 4 s)
-                        const int s = bitrev<16>(p);
-                        scr[k1 + R1 * (r + 4 * s)] = make_float2(cr[u][p], ci[u][p]);
-                    }
-                }
-            }
-            wave_lds_fence();
-            // ---- untangle real spectrum, power, into P[bin][fi] ----------------
-            // X[k] = E + W^k O, X[NC-k] = conj(E - W^k O), E = (Z[k] + conj Z[NC-k]) / 2,
-            // O = -i (Z[k] - conj Z[NC-k]) / 2
-#pragma unroll
-            for (int j = 0; j < G::NPAIR; ++j) {
-                const int k = lane + 64 * j;
-                if (k <= NC / 2) {
-                    const float2 za = scr[k];
-                    const float2 zb = scr[(NC - k) & (NC - 1)];
-                    const float er = 0.5f * (za.x + zb.x), ei = 0.5f * (za.y - zb.y);
-                    const float oR = 0.5f * (za.y + zb.y), oI = -0.5f * (za.x - zb.x);
-                    const float tr = oR * t3r[j] - oI * t3i[j];
-                    const float ti = oR * t3i[j] + oI * t3r[j];
-                    const float ar = er + tr, ai = ei + ti;
-                    const float cr2 = er - tr, ci2 = ei - ti;
-                    P[k * PS + fi] = ar * ar + ai * ai;
-                    P[(NC - k) * PS + fi] = cr2 * cr2 + ci2 * ci2;
-                }
-            }
-            wave_lds_fence();                          // scratch is reused by the next frame
+        for (int n1 = 0; n1 < R1; ++n1) {
+            re[n1] = 0.f;
+            im[n1] = 0.f;
         }
-        __syncthreads();
-
-        // ---- sparse mel projection: lanes = (filter, frame) ----------------------
-        constexpr int MPW = 64 / FPB;                  // filters per wave pass
-        const int fl = lane % FPB, ml = lane / FPB;
-        const int nvalid = min(FPB, a.T - f0);
-        for (int m0 = wave * MPW; m0 < a.n_mels; m0 += WAVES * MPW) {
-            const int m = m0 + ml;
-            const bool ok = m < a.n_mels;
-            const int start = ok ? melmeta[3 * m + 0] : 0;
-            const int len = ok ? melmeta[3 * m + 1] : 0;
-            const int ptr = ok ? melmeta[3 * m + 2] : 0;
-            float acc = 0.f;
-            for (int i = 0; i < len; ++i) acc += melw[ptr + i] * P[(start + i) * PS + fl];
-            if (ok && fl < nvalid) {
-                if (a.flags & SEDMI_MEL_LOG) acc = 10.0f * log10f(fmaxf(acc, 1e-10f));
-                if (a.flags & SEDMI_MEL_NORMALISE) acc = (acc - a.mean[m]) * a.istd[m];
-                a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + f0 + fl] = acc;
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+            re[ROW0 + i] = raw0[i] * w0[i];
+            im[ROW0 + i] = raw1[i] * w1[i];
+        }
+        load_raw(f + stride, raw0, raw1);              // request this wave's next frame
+        dif<R1>(re, im);
+#pragma unroll
+        for (int p = 0; p < R1; ++p) {                 // twiddle, then transpose A: [k1][n2]
+            const float xr = re[p] * t1r[p] - im[p] * t1i[p];
+            const float xi = re[p] * t1i[p] + im[p] * t1r[p];
+            scr[bitrev<R1>(p) * G::STRIDE_A + lane] = make_float2(xr, xi);
+        }
+        wave_lds_fence();
+        // ---- stage 2a: radix-4 over p (n2 = 16 p + q), lane = (q, g) --------
+        float br[R1 / 4][4], bi[R1 / 4][4];
+#pragma unroll
+        for (int i = 0; i < R1 / 4; ++i) {
+            const int k1 = g * (R1 / 4) + i;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float2 v = scr[k1 * G::STRIDE_A + 16 * p + q];
+                br[i][p] = v.x;
+                bi[i][p] = v.y;
             }
         }
-        __syncthreads();                               // P is overwritten by the next tile
+        wave_lds_fence();                              // all reads before scratch is reused
+#pragma unroll
+        for (int i = 0; i < R1 / 4; ++i) {
+            const int k1 = g * (R1 / 4) + i;
+            dif<4>(br[i], bi[i]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {              // twiddle W_64^(q r), transpose B: [q][r*R1 + k1]
+                const int r = bitrev<4>(p);
+                const float xr = br[i][p] * t2r[p] - bi[i][p] * t2i[p];
+                const float xi = br[i][p] * t2i[p] + bi[i][p] * t2r[p];
+                scr[q * G::STRIDE_B + r * R1 + k1] = make_float2(xr, xi);
+            }
+        }
+        wave_lds_fence();
+        // ---- stage 2b: radix-16 over q, one butterfly per (r, k1) ----------
+        constexpr int NB = (4 * R1 + 63) / 64;
+        float cr[NB][16], ci[NB][16];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < 4 * R1) {
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    const float2 v = scr[qq * G::STRIDE_B + idx];
+                    cr[u][qq] = v.x;
+                    ci[u][qq] = v.y;
+                }
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < 4 * R1) {
+                dif<16>(cr[u], ci[u]);
+                const int r = idx / R1, k1 = idx % R1;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {         // natural order Z[k], k = k1 + R1 (r + 4 s)
+                    const int s = bitrev<16>(p);
+                    scr[k1 + R1 * (r + 4 * s)] = make_float2(cr[u][p], ci[u][p]);
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- untangle real spectrum, power --------------------------------
+        // X[k] = E + W^k O, X[NC-k] = conj(E - W^k O), E = (Z[k] + conj Z[NC-k]) / 2,
+        // O = -i (Z[k] - conj Z[NC-k]) / 2
+        float pa[G::NPAIR], pb[G::NPAIR];
+        if constexpr (kT3Const) {
+            // opaque to the optimiser: otherwise the rotated twiddles are loop invariants, get hoisted out
+            // of the frame loop and occupy the very registers this form is meant to free
+            asm volatile("" : "+v"(t3r[0]), "+v"(t3i[0]));
+        }
+#pragma unroll
+        for (int j = 0; j < G::NPAIR; ++j) {
+            const int k = lane + 64 * j;
+            pa[j] = pb[j] = 0.f;
+            if (k <= NC / 2) {
+                const float2 za = scr[k];
+                const float2 zb = scr[(NC - k) & (NC - 1)];
+                const float er = 0.5f * (za.x + zb.x), ei = 0.5f * (za.y - zb.y);
+                const float oR = 0.5f * (za.y + zb.y), oI = -0.5f * (za.x - zb.x);
+                float wr, wi;
+                if constexpr (kT3Const) {
+                    const int ang = j * (16 / R1);                 // units of 2 pi / 32
+                    const float c = cos32(ang), sn = -sin32(ang);  // exp(-i * 2 pi ang / 32)
+                    wr = t3r[0] * c - t3i[0] * sn;
+                    wi = t3r[0] * sn + t3i[0] * c;
+                } else {
+                    wr = t3r[j];
+                    wi = t3i[j];
+                }
+                const float tr = oR * wr - oI * wi;
+                const float ti = oR * wi + oI * wr;
+                const float ar = er + tr, ai = ei + ti;
+                const float cr2 = er - tr, ci2 = ei - ti;
+                pa[j] = ar * ar + ai * ai;
+                pb[j] = cr2 * cr2 + ci2 * ci2;
+            }
+        }
+        wave_lds_fence();                              // every Z read before the scratch becomes the power array
+#pragma unroll
+        for (int j = 0; j < G::NPAIR; ++j) {
+            const int k = lane + 64 * j;
+            if (k <= NC / 2) {
+                pw[k] = pa[j];
+                pw[NC - k] = pb[j];
+            }
+        }
+        if (lane < 8) pw[NC + 1 + lane] = 0.f;
+        wave_lds_fence();
+        // ---- sparse mel projection: lane = filter -----------------------------
+        // weight runs are zero-padded to a multiple of 8 on the host, so eight bins go in flight together
+        // (the reads past a filter's end meet zero weights; pw carries 8 floats of zero padding)
+        for (int m = lane; m < a.n_mels; m += 64) {
+            const int start = melmeta[3 * m + 0], len = melmeta[3 * m + 1], ptr = melmeta[3 * m + 2];
+            float acc0 = 0.f, acc1 = 0.f;
+            for (int i = 0; i < len; i += 8) {
+                const float4 wa = *reinterpret_cast<const float4 *>(melw + ptr + i);
+                const float4 wb = *reinterpret_cast<const float4 *>(melw + ptr + i + 4);
+                const float *pp = pw + start + i;
+                const float p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4], p5 = pp[5], p6 = pp[6], p7 = pp[7];
+                acc0 = fmaf(wa.x, p0, acc0); acc1 = fmaf(wa.y, p1, acc1);
+                acc0 = fmaf(wa.z, p2, acc0); acc1 = fmaf(wa.w, p3, acc1);
+                acc0 = fmaf(wb.x, p4, acc0); acc1 = fmaf(wb.y, p5, acc1);
+                acc0 = fmaf(wb.z, p6, acc0); acc1 = fmaf(wb.w, p7, acc1);
+            }
+            float acc = acc0 + acc1;
+            if (a.flags & SEDMI_MEL_LOG) acc = 10.0f * log10f(fmaxf(acc, 1e-10f));
+            if (a.flags & SEDMI_MEL_NORMALISE) acc = (acc - a.mean[m]) * a.istd[m];
+            a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + t] = acc;
+        }
+        wave_lds_fence();                              // scratch is reused by the next frame
     }
 }
 
-template <int R1, int WAVES, int FPB>
+template <int R1, int WAVES>
 size_t mel_lds_bytes(int n_mels, int nnz) {
     using G = MelGeom<R1>;
-    return sizeof(float2) * G::SCR * WAVES + sizeof(float) * (G::NC + 1) * (FPB + 1) +
-           sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 3 * n_mels;
+    return sizeof(float2) * G::SCR * WAVES + sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 3 * n_mels;
 }
 
 // float64 -> per-bin statistics for the optional normalisation stage
@@ -402,7 +436,7 @@ double mel_to_hz(double m) {
 
 struct sedmi_mel_plan {
     int sr, n_fft, win_length, hop, n_mels, n_bins;
-    int zlo, zhi, nnz;
+    int zlo, zhi, nnz, nnz_real;      // nnz: stored weights incl. the zero padding of each run
     int device, num_cus;
     std::vector<float> fb_dense;   // host copy [n_mels, n_bins]
     float *d_win = nullptr;
@@ -426,7 +460,7 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
 
     auto *p = new sedmi_mel_plan();
     p->sr = sr; p->n_fft = n_fft; p->win_length = win_length; p->hop = hop_length;
-    p->n_mels = n_mels; p->n_bins = 1 + n_fft / 2;
+    p->n_mels = n_mels; p->n_bins = 1 + n_fft / 2; p->nnz_real = 0;
     SEDMI_CHECK_HIP(hipGetDevice(&p->device));
     hipDeviceProp_t prop;
     SEDMI_CHECK_HIP(hipGetDeviceProperties(&prop, p->device));
@@ -465,6 +499,7 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
     p->fb_dense.assign(static_cast<size_t>(n_mels) * nb, 0.f);
     std::vector<int> start(n_mels), len(n_mels), ptr(n_mels);
     std::vector<float> wsp;
+    unsigned used_groups = 0;
     for (int i = 0; i < n_mels; ++i) {
         const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
         const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
@@ -481,8 +516,18 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
         }
         start[i] = first < 0 ? 0 : first;
         len[i] = first < 0 ? 0 : last - first + 1;
+        // the 16-byte weight reads that 16 neighbouring lanes (= filters 16 j .. 16 j + 15) issue together
+        // should fall into 16 different groups of four LDS banks: start each run at the first multiple of
+        // four floats whose bank group no other filter of its 16-group uses yet
+        if (i % 16 == 0) used_groups = 0;
+        while (wsp.size() % 4) wsp.push_back(0.f);
+        while (used_groups >> ((wsp.size() / 4) % 16) & 1u) wsp.insert(wsp.end(), 4, 0.f);
+        used_groups |= 1u << ((wsp.size() / 4) % 16);
         ptr[i] = static_cast<int>(wsp.size());
+        p->nnz_real += len[i];
         for (int k = 0; k < len[i]; ++k) wsp.push_back(p->fb_dense[static_cast<size_t>(i) * nb + start[i] + k]);
+        len[i] = (len[i] + 7) & ~7;                     // the kernel consumes a filter's run eight bins at a time
+        while (wsp.size() < static_cast<size_t>(ptr[i] + len[i])) wsp.push_back(0.f);
     }
     p->nnz = static_cast<int>(wsp.size());
 
@@ -519,20 +564,21 @@ int sedmi_mel_filterbank(const sedmi_mel_plan *p, float *host_out) {
 
 }  // extern "C"
 
-template <int R1, int WAVES, int FPB, int ROW0 = 0, int NROW = R1>
+template <int R1, int WAVES, int ROW0 = 0, int NROW = R1>
 static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
-    a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, FPB));
-    a.total_tiles = n_clips * a.tiles_per_clip;
-    const size_t lds = mel_lds_bytes<R1, WAVES, FPB>(p->n_mels, p->nnz);
+    a.tiles_per_clip = a.T;
+    a.total_tiles = n_clips * a.T;                     // work items are frames
+    const size_t lds = mel_lds_bytes<R1, WAVES>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
-    auto kern = mel_kernel<R1, WAVES, FPB, ROW0, NROW>;
+    auto kern = mel_kernel<R1, WAVES, ROW0, NROW>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    const long grid = std::min<long>(a.total_tiles, 2L * p->num_cus);
+    const long per_cu = std::max<long>(1, std::min<long>(8, (160 * 1024) / static_cast<long>(lds)));
+    const long grid = std::min<long>(sedmi::ceil_div(a.total_tiles, WAVES), per_cu * p->num_cus);
     const double frames = static_cast<double>(n_clips) * a.T;
     sedmi::ProfileScope prof("mel_kernel", stream,
                              frames * (2.5 * p->n_fft * std::log2(static_cast<double>(p->n_fft)) + 3.0 * p->n_bins +
-                                       2.0 * p->nnz),
+                                       2.0 * p->nnz_real),
                              4.0 * (static_cast<double>(n_clips) * a.n_samples + frames * p->n_mels));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, a);
     SEDMI_CHECK_LAUNCH();
@@ -558,12 +604,12 @@ int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, 
     a.mel_w = p->d_w; a.nnz = p->nnz; a.out = out; a.flags = flags; a.mean = mean; a.istd = istd;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->n_fft) {
-        case 1024: return launch_mel<8, 8, 16>(p, a, n_clips, s);
+        case 1024: return launch_mel<8, 4>(p, a, n_clips, s);
         case 2048:
             // window confined to first-stage rows 5..10 (e.g. win 640): specialised instance
-            if (p->zlo >= 5 * 64 && p->zhi <= 11 * 64) return launch_mel<16, 8, 16, 5, 6>(p, a, n_clips, s);
-            return launch_mel<16, 8, 16>(p, a, n_clips, s);
-        default:   return launch_mel<32, 4, 8>(p, a, n_clips, s);
+            if (p->zlo >= 5 * 64 && p->zhi <= 11 * 64) return launch_mel<16, 4, 5, 6>(p, a, n_clips, s);
+            return launch_mel<16, 4>(p, a, n_clips, s);
+        default:   return launch_mel<32, 4>(p, a, n_clips, s);
     }
 }
 
