@@ -252,7 +252,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
 
     // ---- GLU linear, MG m-tiles per wave at a time: z -> hi/lo planes in LDS (they alias the input
     // planes), lin = z . Wg^T on the matrix cores, then gate, pool, store
+    // stores go through a buffer descriptor that spans exactly this clip's output: rows past the end of
+    // the clip (last tile) fall outside it and the hardware drops them, so there is no branch per store
     float *yc = y + clip * static_cast<long>(H) * (W / 2) * COUT;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yc, 0, H * (W / 2) * COUT * 4, 0x00020000);
+    // pooled position of (row h0 + pos / W, column pos % W) is h0 * W/2 + pos / 2 for even pos
+    const int ybase = ((h0 * (W / 2) + 16 * MT * wm + 2 * half) * COUT + ncol) * 4;
     const uint4 *gbp = gp + ncol * 2 + half;
     constexpr int MG = G::MG;
 #pragma unroll
@@ -263,12 +268,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    _Float16 hi, lo;
-                    split_f16(acc[m0 + mt][nt][r], hi, lo);
+                for (int r = 0; r < 16; r += 2) {     // registers r, r + 1 are neighbouring rows: packed converts
+                    unsigned hi, lo;
+                    split2_f16(acc[m0 + mt][nt][r], acc[m0 + mt][nt][r + 1], hi, lo);
                     const int off = (32 * MG * wm + 32 * mt + acc_row(r, half)) * G::ZSB + (ncol + 32 * nt) * 2;
-                    *reinterpret_cast<_Float16 *>(plane_h + off) = hi;
-                    *reinterpret_cast<_Float16 *>(plane_l + off) = lo;
+                    *reinterpret_cast<unsigned short *>(plane_h + off) = static_cast<unsigned short>(hi);
+                    *reinterpret_cast<unsigned short *>(plane_l + off) = static_cast<unsigned short>(lo);
+                    *reinterpret_cast<unsigned short *>(plane_h + off + G::ZSB) = static_cast<unsigned short>(hi >> 16);
+                    *reinterpret_cast<unsigned short *>(plane_l + off + G::ZSB) = static_cast<unsigned short>(lo >> 16);
                 }
         __syncthreads();
         f32x16 lin[MG][NT];
@@ -295,10 +302,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
                 for (int r = 0; r < 16; r += 2) {
                     const float o0 = fmaf(lin[mt][nt][r], gsc, bias) * sigmoidf_fast(acc[m0 + mt][nt][r]);
                     const float o1 = fmaf(lin[mt][nt][r + 1], gsc, bias) * sigmoidf_fast(acc[m0 + mt][nt][r + 1]);
-                    const int pos = 32 * MT * wm + 32 * (m0 + mt) + acc_row(r, half);
-                    const int hr = h0 + pos / W;
-                    if (hr < H)
-                        yc[(static_cast<long>(hr) * (W / 2) + (pos % W) / 2) * COUT + ncol + 32 * nt] = 0.5f * (o0 + o1);
+                    // acc_row(r, half) / 2 = (r & 3) / 2 + 4 * (r >> 2) + 2 * half for even r
+                    const int yoff = ((16 * (m0 + mt) + (r & 3) / 2 + 4 * (r >> 2)) * COUT + 32 * nt) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (o0 + o1)), yrsrc,
+                                                          ybase + yoff, 0, 0);
                 }
         }
     }

@@ -45,6 +45,9 @@ namespace {
 
 #include "mfma_common.h"
 #include "conv_split.h"
+#ifndef CONV_MT
+#define CONV_MT 4
+#endif
 
 // One wave's [64 x 32*NT] += A[64 x 8*kgroups] * B over `kgroups` groups of 8
 // contraction indices.  a0/a1: this lane's row of the two 32-row A tiles
@@ -705,9 +708,9 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             if ((rc = launch_conv_split<16, 32, 64, 4, 2, 16>(m, 1, actA, actB, nc, Tp, s))) return rc;
             if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<64, 128, 16, 2, 4, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 8, 2, 4, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 4, 2, 4, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<64, 128, 16, 2, CONV_MT, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 8, 2, CONV_MT, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 4, 2, CONV_MT, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
             if ((rc = launch_conv_split<128, 128, 2, 2, 4, 16>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
             continue;
         }
