@@ -607,7 +607,7 @@ struct sedmi_crnn {
     float *d_gp[SEDMI_CRNN_LAYERS] = {}, *d_gb[SEDMI_CRNN_LAYERS] = {};
     // split-f16 variants (blocks 1..6): packed hi/lo weights, scales with the power-of-two weight scale undone
     uint16_t *d_wps[SEDMI_CRNN_LAYERS] = {}, *d_gps[SEDMI_CRNN_LAYERS] = {};
-    float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {};
+    float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {}, *d_gbh[SEDMI_CRNN_LAYERS] = {};
     uint16_t *d_wihs[2] = {};          // split-f16 GRU input-projection weights
     float wih_oscale[2] = {1.f, 1.f};
     uint16_t *d_whhs[2] = {};          // split-f16 GRU recurrent weights, both directions
@@ -656,7 +656,7 @@ int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, 
                              pos * 4.0 * (CIN + COUT / 2.0));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_clips * tiles)), dim3(256), lds, s, x,
                        reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_t[layer],
-                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gb[layer], y, H, tiles);
+                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
@@ -878,10 +878,15 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
             auto gps = pack_split(co / 16, co, Sg, [&](int kidx, int k16, int n) {
                 return gsrc[static_cast<size_t>(n) * co + kidx * 16 + k16];
             });
-            std::vector<float> ss(co), gs(co, std::ldexp(1.0f, -Sg));
-            for (int c = 0; c < co; ++c) ss[c] = std::ldexp(s[i][c], -S);
+            // the average pool's factor 1/2 rides along in the GLU scale and bias of the split path
+            std::vector<float> ss(co), gs(co, std::ldexp(1.0f, -Sg - 1)), gbh(co);
+            for (int c = 0; c < co; ++c) {
+                ss[c] = std::ldexp(s[i][c], -S);
+                gbh[c] = 0.5f * w->glu_b[i][c];
+            }
             if ((rc = sedmi::upload(&m->d_wps[i], wps)) || (rc = sedmi::upload(&m->d_gps[i], gps)) ||
-                (rc = sedmi::upload(&m->d_ss[i], ss)) || (rc = sedmi::upload(&m->d_gs[i], gs)))
+                (rc = sedmi::upload(&m->d_ss[i], ss)) || (rc = sedmi::upload(&m->d_gs[i], gs)) ||
+                (rc = sedmi::upload(&m->d_gbh[i], gbh)))
                 return fail(rc);
         }
         if ((rc = sedmi::upload(&m->d_wp[i], wp)) || (rc = sedmi::upload(&m->d_s[i], s[i])) ||
@@ -945,6 +950,7 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
         (void)hipFree(m->d_wp[i]); (void)hipFree(m->d_s[i]); (void)hipFree(m->d_t[i]);
         (void)hipFree(m->d_gp[i]); (void)hipFree(m->d_gb[i]);
         (void)hipFree(m->d_wps[i]); (void)hipFree(m->d_gps[i]); (void)hipFree(m->d_ss[i]); (void)hipFree(m->d_gs[i]);
+        (void)hipFree(m->d_gbh[i]);
     }
     for (int l = 0; l < 2; ++l) {
         (void)hipFree(m->d_wihs[l]);
