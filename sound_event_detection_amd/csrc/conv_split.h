@@ -211,9 +211,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     };
     load_chunk(0);
     for (int c = 0; c < G::NCHUNK; ++c) {
-#ifdef SPLIT_NO_CHUNK_PREFETCH
-        if (c) load_chunk(c);
-#endif
         if (c) __syncthreads();                        // every wave is done reading the previous chunk
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -230,9 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             }
         }
         __syncthreads();
-#ifndef SPLIT_NO_CHUNK_PREFETCH
         if (c + 1 < G::NCHUNK) load_chunk(c + 1);
-#endif
         split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT,
                                        [](int i) {
                                            const int tap = i / G::KS, ks = i % G::KS;
