@@ -79,38 +79,40 @@ __global__ __launch_bounds__(256, 2) void shake_conv1_kernel(const float *__rest
             patch[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[static_cast<long>(yy) * W + xx] : 0.f;
         }
     }
-    float o[2][16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float z[2][2];                    // [GLU half][position]
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int co = c + 16 * hf;
-            float wv[28];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const float4 q = wsm[co][j];
-                wv[4 * j] = q.x; wv[4 * j + 1] = q.y; wv[4 * j + 2] = q.z; wv[4 * j + 3] = q.w;
-            }
-            const float4 st = wsm[co][7];
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 25; ++k) {
-                a0 = fmaf(patch[k / 5][k % 5], wv[k], a0);
-                a1 = fmaf(patch[k / 5][k % 5 + 1], wv[k], a1);
-            }
-            z[hf][0] = fmaf(a0, st.x, st.y);
-            z[hf][1] = fmaf(a1, st.x, st.y);
-            __builtin_amdgcn_sched_barrier(0);      // keep each channel's weight reads next to their use
-        }
-        o[0][c] = z[0][0] * sigmoidf_fast(z[1][0]);
-        o[1][c] = z[0][1] * sigmoidf_fast(z[1][1]);
-    }
     float4 *dst = reinterpret_cast<float4 *>(u + ((b * H + yi) * static_cast<long>(W) + xi) * 16);
+    // four output channels per trip of a rolled loop: a fully unrolled channel loop lets the
+    // compiler pull every weight read to the top and spill
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        float o[2][4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+        for (int c4 = 0; c4 < 4; ++c4) {
+            float z[2][2];                    // [GLU half][position]
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dst[p * 4 + v] = make_float4(o[p][4 * v], o[p][4 * v + 1], o[p][4 * v + 2], o[p][4 * v + 3]);
+            for (int hf = 0; hf < 2; ++hf) {
+                const float4 *wr = wsm[4 * g + c4 + 16 * hf];
+                float wv[28];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float4 q = wr[j];
+                    wv[4 * j] = q.x; wv[4 * j + 1] = q.y; wv[4 * j + 2] = q.z; wv[4 * j + 3] = q.w;
+                }
+                const float4 st = wr[7];
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 25; ++k) {
+                    a0 = fmaf(patch[k / 5][k % 5], wv[k], a0);
+                    a1 = fmaf(patch[k / 5][k % 5 + 1], wv[k], a1);
+                }
+                z[hf][0] = fmaf(a0, st.x, st.y);
+                z[hf][1] = fmaf(a1, st.x, st.y);
+            }
+            o[0][c4] = z[0][0] * sigmoidf_fast(z[1][0]);
+            o[1][c4] = z[0][1] * sigmoidf_fast(z[1][1]);
+        }
+        dst[g] = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+        dst[4 + g] = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+    }
 }
 
 // ---------------------------------------------------------------------------
