@@ -207,17 +207,27 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     }
     __syncthreads();
 
-    // frames are dealt to waves round robin over the whole launch: neighbouring waves work on
-    // neighbouring frames of a clip at about the same time, so the overlapping input samples and
-    // the partially written output lines meet in L2
-    const long total_frames = a.total_tiles;           // clips * T
-    const long stride = static_cast<long>(gridDim.x) * WAVES;
+    // A workgroup takes blocks of FB = 32 consecutive frames of one clip and its WAVES waves walk a
+    // block WAVES frames at a time: the 4-byte mel-major writes of those frames then fill whole lines
+    // in ONE L2 (frames dealt across workgroups land in different XCDs, whose L2s cannot merge them:
+    // that cost 4x the output bytes in HBM writes), and the overlapping input samples are re-read from
+    // the same CU's caches.
+    constexpr int FB = 32, ROUNDS = FB / WAVES;
+    const int blocks_per_clip = a.tiles_per_clip;
+    const long total_blocks = a.total_tiles;
+    // it-th frame of this wave: block blockIdx.x + (it / ROUNDS) * gridDim.x, frame (it % ROUNDS) * WAVES + wave in it
+    auto locate = [&](long it, long &clip, int &t) {
+        const long blk = blockIdx.x + (it / ROUNDS) * static_cast<long>(gridDim.x);
+        clip = blk / blocks_per_clip;
+        t = static_cast<int>(blk - clip * blocks_per_clip) * FB + static_cast<int>(it % ROUNDS) * WAVES + wave;
+        return blk < total_blocks;
+    };
     // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use
-    auto load_raw = [&](long f, float (&r0)[NROW], float (&r1)[NROW]) {
-        const bool live = f < total_frames;
-        const long clip = live ? f / a.T : 0;
-        const int t = static_cast<int>(f - clip * a.T);
-        const float *yc = a.y + clip * a.n_samples;
+    auto load_raw = [&](long it, float (&r0)[NROW], float (&r1)[NROW]) {
+        long clip;
+        int t;
+        const bool live = locate(it, clip, t) && t < a.T;
+        const float *yc = a.y + (live ? clip : 0) * a.n_samples;
         const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
@@ -227,12 +237,12 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
         }
     };
     float raw0[NROW], raw1[NROW];
-    long f = static_cast<long>(blockIdx.x) * WAVES + wave;
-    load_raw(f, raw0, raw1);
+    load_raw(0, raw0, raw1);
 
-    for (; f < total_frames; f += stride) {
-        const long clip = f / a.T;
-        const int t = static_cast<int>(f - clip * a.T);
+    for (long it = 0;; ++it) {
+        long clip;
+        int t;
+        if (!locate(it, clip, t)) break;
         // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
         float re[R1], im[R1];
 #pragma unroll
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             re[ROW0 + i] = raw0[i] * w0[i];
             im[ROW0 + i] = raw1[i] * w1[i];
         }
-        load_raw(f + stride, raw0, raw1);              // request this wave's next frame
+        load_raw(it + 1, raw0, raw1);                  // request this wave's next frame
+        if (t >= a.T) continue;                        // wave-uniform: past the end of the clip (last block)
         dif<R1>(re, im);
 #pragma unroll
         for (int p = 0; p < R1; ++p) {                 // twiddle, then transpose A: [k1][n2]
@@ -566,15 +577,15 @@ int sedmi_mel_filterbank(const sedmi_mel_plan *p, float *host_out) {
 
 template <int R1, int WAVES, int ROW0 = 0, int NROW = R1>
 static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
-    a.tiles_per_clip = a.T;
-    a.total_tiles = n_clips * a.T;                     // work items are frames
+    a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, 32));     // work items: blocks of 32 frames
+    a.total_tiles = n_clips * a.tiles_per_clip;
     const size_t lds = mel_lds_bytes<R1, WAVES>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
     auto kern = mel_kernel<R1, WAVES, ROW0, NROW>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const long per_cu = std::max<long>(1, std::min<long>(8, (160 * 1024) / static_cast<long>(lds)));
-    const long grid = std::min<long>(sedmi::ceil_div(a.total_tiles, WAVES), per_cu * p->num_cus);
+    const long grid = std::min<long>(a.total_tiles, per_cu * p->num_cus);
     const double frames = static_cast<double>(n_clips) * a.T;
     sedmi::ProfileScope prof("mel_kernel", stream,
                              frames * (2.5 * p->n_fft * std::log2(static_cast<double>(p->n_fft)) + 3.0 * p->n_bins +
