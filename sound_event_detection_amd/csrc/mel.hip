@@ -125,6 +125,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// four floats stored as one 16-byte access that is only 4-byte aligned (dword alignment is all a
+// multi-dword global access needs)
+typedef float Float4U __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int R1>
 struct MelGeom {
     static constexpr int NC = 64 * R1;
@@ -207,19 +211,21 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     }
     __syncthreads();
 
-    // A workgroup takes blocks of FB = 32 consecutive frames of one clip and its WAVES waves walk a
-    // block WAVES frames at a time: the 4-byte mel-major writes of those frames then fill whole lines
-    // in ONE L2 (frames dealt across workgroups land in different XCDs, whose L2s cannot merge them:
-    // that cost 4x the output bytes in HBM writes), and the overlapping input samples are re-read from
-    // the same CU's caches.
+    // A workgroup takes blocks of FB = 32 consecutive frames of one clip, each wave FB / WAVES consecutive
+    // frames of it: the overlapping input samples are re-read from the same CU's caches, and a lane
+    // collects its filter's value over four frames before it writes them as one 16-byte piece of the
+    // mel-major row (single 4-byte writes cost 4-5x the output bytes in HBM write traffic).
     constexpr int FB = 32, ROUNDS = FB / WAVES;
+    static_assert(ROUNDS % 4 == 0, "frames per wave and block must be a multiple of 4");
+    float keep[2][4];              // [filter pass][frame of the group of four]; later passes write directly
     const int blocks_per_clip = a.tiles_per_clip;
     const long total_blocks = a.total_tiles;
     // it-th frame of this wave: block blockIdx.x + (it / ROUNDS) * gridDim.x, frame (it % ROUNDS) * WAVES + wave in it
     auto locate = [&](long it, long &clip, int &t) {
         const long blk = blockIdx.x + (it / ROUNDS) * static_cast<long>(gridDim.x);
         clip = blk / blocks_per_clip;
-        t = static_cast<int>(blk - clip * blocks_per_clip) * FB + static_cast<int>(it % ROUNDS) * WAVES + wave;
+        // a wave owns ROUNDS consecutive frames of the block, so that four of its results make one 16-byte store
+        t = static_cast<int>(blk - clip * blocks_per_clip) * FB + wave * ROUNDS + static_cast<int>(it % ROUNDS);
         return blk < total_blocks;
     };
     // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use
@@ -387,7 +393,33 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             float acc = acc0 + acc1;
             if (a.flags & SEDMI_MEL_LOG) acc = 10.0f * log10f(fmaxf(acc, 1e-10f));
             if (a.flags & SEDMI_MEL_NORMALISE) acc = (acc - a.mean[m]) * a.istd[m];
-            a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + t] = acc;
+            const int j = t & 3, pass = m >> 6;
+            if (pass < 2) {
+#pragma unroll
+                for (int pp2 = 0; pp2 < 2; ++pp2)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (pp2 == pass && jj == j) keep[pp2][jj] = acc;
+            } else {
+                a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + t] = acc;
+            }
+        }
+        if ((t & 3) == 3 || t + 1 >= a.T) {            // last frame of its group of four (or of the clip)
+            const int t0 = t & ~3, nl = t - t0 + 1;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int m = pass * 64 + lane;
+                if (m < a.n_mels) {
+                    float *dst = a.out + (clip * a.n_mels + m) * static_cast<long>(a.T) + t0;
+                    if (nl == 4) {                     // rows are T floats apart: 4-byte aligned only
+                        *reinterpret_cast<Float4U *>(dst) = Float4U{keep[pass][0], keep[pass][1], keep[pass][2], keep[pass][3]};
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj)
+                            if (jj < nl) dst[jj] = keep[pass][jj];
+                    }
+                }
+            }
         }
         wave_lds_fence();                              // scratch is reused by the next frame
     }
