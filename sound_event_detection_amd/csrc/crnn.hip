@@ -782,7 +782,8 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
 int check_shape(const sedmi_crnn *m, int64_t n_clips, int64_t T) {
     SEDMI_REQUIRE(m != nullptr, "model is null");
     SEDMI_REQUIRE(n_clips >= 0 && T >= 0, "negative size");
-    SEDMI_REQUIRE(T < (1 << 30) && n_clips < (1LL << 31), "shape too large");
+    // per-clip activations are addressed with 32-bit byte offsets (4096 B per frame pair in blocks 0 and 1)
+    SEDMI_REQUIRE(T <= 1000000 && n_clips < (1LL << 31), "shape too large: at most 1 000 000 frames per clip");
     return SEDMI_OK;
 }
 
