@@ -54,7 +54,7 @@ struct SplitGeom {
     static constexpr int ZSB = COUT * 2 + 16;
     // m-tiles per wave that go through the GLU together: one where the accumulators already fill the
     // register file (two would spill ~90 B per lane, and spills are written through to HBM), else two
-    static constexpr int MG = (MT >= 4 || MT < 2) ? 1 : 2;
+    static constexpr int MG = NT == 1 ? (MT >= 2 ? 2 : 1) : ((MT >= 4 || MT < 2) ? 1 : 2);
     static constexpr int ZROWS = WAVES_M * 32 * MG;      // rows of the z planes (one GLU phase)
     static constexpr int PLANE_Z = ZROWS * ZSB;
     static constexpr int LDS_BYTES = 2 * (PLANE_A > PLANE_Z ? PLANE_A : PLANE_Z);

@@ -45,8 +45,14 @@ namespace {
 
 #include "mfma_common.h"
 #include "conv_split.h"
+// wave tiling of the 128-channel blocks: CONV_WM x (4 / CONV_WM) waves, CONV_MT m-tiles per wave.
+// 2 x 2 waves with 4 x 2 tiles measured best; 1 x 4 waves with 8 x 1 tiles (half the weight loads per
+// wave, twice the LDS reads) ties within 2 %.
 #ifndef CONV_MT
 #define CONV_MT 4
+#endif
+#ifndef CONV_WM
+#define CONV_WM 2
 #endif
 
 // One wave's [64 x 32*NT] += A[64 x 8*kgroups] * B over `kgroups` groups of 8
@@ -708,10 +714,10 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             if ((rc = launch_conv_split<16, 32, 64, 4, 2, 16>(m, 1, actA, actB, nc, Tp, s))) return rc;
             if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<64, 128, 16, 2, CONV_MT, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 8, 2, CONV_MT, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 4, 2, CONV_MT, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 2, 2, 4, 16>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<64, 128, 16, CONV_WM, CONV_MT, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 8, CONV_WM, CONV_MT, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 4, CONV_WM, CONV_MT, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
+            if ((rc = launch_conv_split<128, 128, 2, CONV_WM, CONV_MT, 16>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
             continue;
         }
         if ((rc = launch_conv<16, 32, 64>(m, 1, actA, actB, nc, Tp, s))) return rc;
