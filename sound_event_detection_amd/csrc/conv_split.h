@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const uint4 *__restrict__ gp,      // packed split GLU weights [COUT/16][2][COUT][16] f16
     const float *__restrict__ g_s, const float *__restrict__ gb,      // lin / 2 = acc * g_s + gb (pool factor folded in)
     float *__restrict__ y,             // [clip][H][W/2][COUT] f32
-    int H, int tiles_per_clip) {
+    int H, int tiles_per_clip, unsigned n_tiles) {
     using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,8 +161,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
-    const long clip = blockIdx.x / tiles_per_clip;
-    const int h0 = static_cast<int>(blockIdx.x % tiles_per_clip) * G::TH;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2, and vertically
+    // neighbouring tiles share two halo rows: give every XCD a contiguous range of tiles, so that
+    // workgroups b and b + 8, which it runs back to back, are neighbours and the halo comes from L2.
+    const unsigned per_xcd = (gridDim.x + 7) / 8;
+    const unsigned tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= n_tiles) return;
+    const long clip = tile / tiles_per_clip;
+    const int h0 = static_cast<int>(tile % tiles_per_clip) * G::TH;
     const float *xc = x + clip * static_cast<long>(H) * W * CIN;
 
     // zero the halo columns once (staging never writes them)

@@ -660,9 +660,11 @@ int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, 
     const double pos = static_cast<double>(n_clips) * H * W;
     sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
                              pos * 4.0 * (CIN + COUT / 2.0));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_clips * tiles)), dim3(256), lds, s, x,
+    const unsigned n_tiles = static_cast<unsigned>(n_clips * tiles);
+    hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), lds, s, x,
                        reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_t[layer],
-                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles);
+                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles,
+                       n_tiles);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const float *__restrict__ s2, const float *__restrict__ t2,     // MODE_GATE: second BatchNorm affine
     float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2];
                                       // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine)
-    int H, int W, int tiles_x, int tiles_y) {
+    int H, int W, int tiles_x, int tiles_y, unsigned n_tiles) {
     using G = Conv2dGeom<CIN, N, CCH>;
     constexpr int NT = G::NT, MT = 2, CO = N / 2;
     static_assert(MODE != MODE_GATE || CIN == CO, "the gate multiplies the conv input channel by channel");
@@ -164,7 +164,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     char *plane_h = smem, *plane_l = smem + G::PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col32 = lane & 31;
-    int bid = blockIdx.x;
+    // workgroup b runs on XCD b % 8 and every XCD has its own L2: hand each XCD a contiguous range of
+    // tiles so that the tiles it runs back to back are neighbours and share their halos through L2
+    const unsigned per_xcd = (gridDim.x + 7) / 8;
+    int bid = static_cast<int>((blockIdx.x % 8) * per_xcd + blockIdx.x / 8);
+    if (static_cast<unsigned>(bid) >= n_tiles) return;
     const int tx0 = (bid % tiles_x) * C2_TC;
     bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * C2_TR;
@@ -907,8 +911,9 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
                              pos * 4.0 * (CIN + (MODE == MODE_BIAS ? N : MODE == MODE_GLU ? N / 2.0
                                                                                         : CIN + N / 2.0 / (PH * PW))));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n * tiles_x * tiles_y)), dim3(256), G::LDS_BYTES, s, x,
-                       reinterpret_cast<const uint4 *>(wp), es, et, alpha, s2, t2, y, H, W, tiles_x, tiles_y);
+    const unsigned n_tiles = static_cast<unsigned>(n * tiles_x * tiles_y);
+    hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), G::LDS_BYTES, s, x,
+                       reinterpret_cast<const uint4 *>(wp), es, et, alpha, s2, t2, y, H, W, tiles_x, tiles_y, n_tiles);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
