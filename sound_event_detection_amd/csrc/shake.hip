@@ -313,15 +313,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float *__restrict__ A, long lda,
                                                            const uint4 *__restrict__ bpk, int N, int K,
                                                            const float *__restrict__ bias, float oscale,
-                                                           float *__restrict__ C, long ldc, long M, int relu) {
+                                                           float *__restrict__ C, long ldc, long M, int relu,
+                                                           unsigned m_tiles, unsigned n_tiles) {
     constexpr int KC = 128, PSB = KC * 2 + 16, PLANE = 128 * PSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = static_cast<long>(blockIdx.x) * 128;
-    const int ncol = blockIdx.y * 128 + wn * 64 + col32;
+    // Tile order.  Workgroup b runs on XCD b % 8, so XCD x takes the contiguous logical range
+    // [x * per_xcd, (x + 1) * per_xcd); inside it, tiles go in groups of 8 row blocks x all column
+    // blocks, row block fastest: the ~64 tiles an XCD works on at one time form an 8 x 8 patch whose
+    // A and B panels of the current K chunk (1 MB) are shared through its L2 instead of each tile
+    // streaming its own panels from HBM.
+    const unsigned per_xcd = (gridDim.x + 7) / 8;
+    const unsigned logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (logical >= m_tiles * n_tiles) return;
+    constexpr unsigned GM = 8;
+    const unsigned group = logical / (GM * n_tiles), in_group = logical % (GM * n_tiles);
+    const unsigned rows_in_group = min(GM, m_tiles - group * GM);
+    const unsigned tile_m = group * GM + in_group % rows_in_group, tile_n = in_group / rows_in_group;
+    const long m0 = static_cast<long>(tile_m) * 128;
+    const int ncol = tile_n * 128 + wn * 64 + col32;
     f32x16 acc[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -953,9 +966,10 @@ int launch_linear(const char *name, const LinearDev &L, const float *A, float *C
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     sedmi::ProfileScope prof(name, s, 2.0 * rows * L.N * static_cast<double>(L.K), 4.0 * rows * (L.N + static_cast<double>(L.K)));
-    hipLaunchKernelGGL(gemm_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), L.N / 128), dim3(256), lds, s,
+    const unsigned m_tiles = static_cast<unsigned>(sedmi::ceil_div(rows, 128)), n_tiles = L.N / 128;
+    hipLaunchKernelGGL(gemm_split_kernel, dim3((m_tiles * n_tiles + 7) / 8 * 8), dim3(256), lds, s,
                        A, static_cast<long>(L.K), reinterpret_cast<const uint4 *>(L.w), L.N, L.K, L.b, L.oscale, Cout,
-                       static_cast<long>(L.N), rows, relu ? 1 : 0);
+                       static_cast<long>(L.N), rows, relu ? 1 : 0, m_tiles, n_tiles);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
