@@ -10,9 +10,10 @@ resident in HBM.  `value` = clips / second, whole job (all ranks).
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Clips are independent, so every rank runs the same per-GPU batch (weak
-scaling).  With N > 1 the timed step ends with an all-gather of the frame
-probabilities over RCCL — the one exchange the path has when its caller wants
-every prediction everywhere; --no-gather drops it.
+scaling) and the timed step has no collective: each rank decodes the events of
+its own clips, as the reference decodes file by file.  --gather-probs adds an
+all-gather of the frame probabilities over RCCL to the step, for a caller that
+wants every prediction on every rank.
 
 Rank 0 prints ONE JSON line carrying, besides the contract fields,
   roofline      the dominant kernel's achieved algorithmic rate vs its MI355X
@@ -105,7 +106,8 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=192, help="clips of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=["split_f16", "f32"], default=None,
                     help="arithmetic of the conv / GRU-input contractions (default: the library default, split_f16)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of frame probabilities (N > 1)")
+    ap.add_argument("--gather-probs", action="store_true",
+                    help="end every step with an all-gather of the frame probabilities (N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +131,7 @@ def main():
         model.conv_precision = args.precision
     pipe = SedPipeline(model, sr=SR, n_fft=N_FFT, n_mels=N_MELS, hop_length=HOP, win_length=WIN)
     y = make_clips(args.clips, rank, device)
-    gather = world > 1 and not args.no_gather
+    gather = world > 1 and args.gather_probs
     gathered = None
 
     def step():
