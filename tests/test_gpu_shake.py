@@ -172,3 +172,26 @@ def test_basic_rcnn_ragged_and_other_width_vs_oracle():
     assert m(torch.zeros(0, 10, 40, device="cuda")).shape == (0, 5, 4)
     with pytest.raises(ValueError):
         m(torch.zeros(1, 10, 64, device="cuda"))
+
+
+def test_transformer_long_recording_vs_oracle(tmodel):
+    # 24 s of AST-shaped features: 600 tokens = 5 query tiles x 19 key blocks (the last one partial)
+    from oracle import shake
+    sd = synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0)
+    x = torch.from_numpy(synth.synth_shake_feats(11, 1, 2400))
+    al = [0.35, 0.55, 0.75]
+    want = shake.shake_transformer_forward(sd, x, al).numpy()
+    got = tmodel(x.cuda(), al).cpu().numpy()
+    assert got.shape == want.shape == (1, 600, 10)
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
+def test_rcnn_long_recording_vs_oracle(model):
+    from oracle import shake
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    x = torch.from_numpy(synth.synth_shake_feats(12, 1, 2400))
+    al = [0.65, 0.15, 0.45]
+    want = shake.shake_rcnn_forward(sd, x, al).numpy()
+    got = model(x.cuda(), al).cpu().numpy()
+    assert got.shape == want.shape == (1, 600, 10)
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
