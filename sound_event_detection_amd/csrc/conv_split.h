@@ -18,6 +18,19 @@
 #ifndef SPLIT_BDIST
 #define SPLIT_BDIST 1
 #endif
+#ifdef SPLIT_TIMING
+// diagnostic build only: per-layer sums of s_memtime ticks spent in each section of conv_split_kernel
+// (wave 0 of every workgroup), read back through sedmi_debug_split_ticks
+__device__ unsigned long long g_split_ticks[6][12];   // [9] tiles, [10] min start, [11] max end
+#define SPLIT_TICK(sec)                                                 \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        tick_acc[sec] += now_ - tick_last;                              \
+        tick_last = now_;                                               \
+    } while (0)
+#else
+#define SPLIT_TICK(sec) do { } while (0)
+#endif
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
@@ -57,7 +70,9 @@ struct SplitGeom {
     static constexpr int MG = NT == 1 ? (MT >= 2 ? 2 : 1) : ((MT >= 4 || MT < 2) ? 1 : 2);
     static constexpr int ZROWS = WAVES_M * 32 * MG;      // rows of the z planes (one GLU phase)
     static constexpr int PLANE_Z = ZROWS * ZSB;
-    static constexpr int LDS_BYTES = 2 * (PLANE_A > PLANE_Z ? PLANE_A : PLANE_Z);
+    static constexpr int NPHASE = MT / MG;               // GLU phases; their z planes are double-buffered
+    static constexpr int Z_BYTES = (NPHASE > 1 ? 4 : 2) * PLANE_Z;
+    static constexpr int LDS_BYTES = 2 * PLANE_A > Z_BYTES ? 2 * PLANE_A : Z_BYTES;
     static constexpr int NCHUNK = CIN / CCH;
     static constexpr int KS = CCH / 16;                  // k-steps per tap per chunk
     static constexpr int KSTEPS = 9 * CIN / 16;
@@ -88,9 +103,18 @@ __device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int 
 // already offset by 16*(lane>>5)); the weights come in registers.  Before the last m-tile's MFMAs are
 // issued, m-tile 0 of the NEXT step (LDS offset next_off, < 0 for none) is requested into (ph, pl),
 // so that its LDS latency is covered by those MFMAs rather than paid at the head of the next step.
-template <int MT, int NT>
+//
+// hook(slot) runs after every MFMA (slot = running MFMA index, slot0 + 3 * (mt * NT + nt) + 0..2) and is
+// pinned there: vector-ALU work issued between the MFMAs of a wave overlaps with the MFMAs of the other
+// wave on the SIMD, while a long run of pure vector work next to a long run of MFMAs does not.
+struct SplitNoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int MT, int NT, typename Hook = SplitNoHook>
 __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
-                                           int a_off, int next_off, const SplitB<NT> &b, f16x8 &ph, f16x8 &pl) {
+                                           int a_off, int next_off, const SplitB<NT> &b, f16x8 &ph, f16x8 &pl,
+                                           int slot0 = 0, Hook hook = Hook()) {
+    constexpr bool HOOKED = !__is_same(Hook, SplitNoHook);
     f16x8 vah[MT], val[MT];
     vah[0] = ph;
     val[0] = pl;
@@ -111,9 +135,13 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const int slot = slot0 + 3 * (mt * NT + nt);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
+            if (HOOKED) { hook(slot); __builtin_amdgcn_sched_barrier(0); }
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.l[nt], acc[mt][nt], 0, 0, 0);
+            if (HOOKED) { hook(slot + 1); __builtin_amdgcn_sched_barrier(0); }
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
+            if (HOOKED) { hook(slot + 2); __builtin_amdgcn_sched_barrier(0); }
         }
     }
 }
@@ -122,9 +150,9 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
 // before the MFMAs of step i issue (their latency is several hundred cycles).
 // a_off(i) = LDS byte offset of step i relative to ah/al; N = columns of the packed weight matrix
 // (B advances by 4*N uint4 per k-step: 2 planes x N columns x 32 B).
-template <int MT, int NT, int NSTEPS, typename AOff>
+template <int MT, int NT, int NSTEPS, typename AOff, typename Hook = SplitNoHook>
 __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
-                                           const uint4 *b, int N, AOff a_off) {
+                                           const uint4 *b, int N, AOff a_off, Hook hook = Hook()) {
     const int BS = N * 4, n2 = N * 2;
     // weights are requested SPLIT_BDIST k-steps ahead of their use, through a ring of register buffers
     constexpr int D = SPLIT_BDIST, NB = D + 1;
@@ -140,7 +168,8 @@ __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&
         // scheduler sinks every load to just above its first use and the wave stalls on each one
         if (i + D < NSTEPS) split_load_b<NT>(bb[(i + D) % NB], b + (i + D) * BS, n2);
         __builtin_amdgcn_sched_barrier(0);
-        split_step<MT, NT>(acc, ah, al, a_off(i), i + 1 < NSTEPS ? a_off(i + 1) : -1, bb[i % NB], ph, pl);
+        split_step<MT, NT, Hook>(acc, ah, al, a_off(i), i + 1 < NSTEPS ? a_off(i + 1) : -1, bb[i % NB], ph, pl,
+                                 i * 3 * MT * NT, hook);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -167,6 +196,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const unsigned per_xcd = (gridDim.x + 7) / 8;
     const unsigned tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile >= n_tiles) return;
+#ifdef SPLIT_TIMING
+    unsigned long long tick_acc[10] = {}, tick_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long tick_first = tick_last;
+#endif
     const long clip = tile / tiles_per_clip;
     const int h0 = static_cast<int>(tile % tiles_per_clip) * G::TH;
     const float *xc = x + clip * static_cast<long>(H) * W * CIN;
@@ -218,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         }
     };
     load_chunk(0);
+    SPLIT_TICK(0);
     for (int c = 0; c < G::NCHUNK; ++c) {
         if (c) __syncthreads();                        // every wave is done reading the previous chunk
+        SPLIT_TICK(1);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
@@ -235,12 +270,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             }
         }
         __syncthreads();
+        SPLIT_TICK(2);
         if (c + 1 < G::NCHUNK) load_chunk(c + 1);
         split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT,
                                        [](int i) {
                                            const int tap = i / G::KS, ks = i % G::KS;
                                            return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
                                        });
+        SPLIT_TICK(3);
     }
 
     // ---- BatchNorm affine; z stays in the accumulators and goes to LDS as hi/lo planes
@@ -253,8 +290,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], sc, sh);
     }
 
-    // ---- GLU linear, MG m-tiles per wave at a time: z -> hi/lo planes in LDS (they alias the input
-    // planes), lin = z . Wg^T on the matrix cores, then gate, pool, store
+    SPLIT_TICK(4);
+    // ---- GLU: lin = z . Wg^T on the matrix cores, out = lin * sigmoid(z), pooled over column pairs.
+    // MG m-tiles per wave go through it at a time (a "phase").  z reaches the matrix cores as hi/lo f16
+    // planes in LDS (they alias the input planes; two buffers when there is more than one phase).
+    // Everything on the vector ALU that does not depend on the phase's own GEMM -- the sigmoid of the
+    // phase's z (in place, in the accumulators) and the split of the NEXT phase's z -- is issued between
+    // the MFMAs of that GEMM, a few instructions after each.
     // stores go through a buffer descriptor that spans exactly this clip's output: rows past the end of
     // the clip (last tile) fall outside it and the hardware drops them, so there is no branch per store
     float *yc = y + clip * static_cast<long>(H) * (W / 2) * COUT;
@@ -262,25 +304,45 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     // pooled position of (row h0 + pos / W, column pos % W) is h0 * W/2 + pos / 2 for even pos
     const int ybase = ((h0 * (W / 2) + 16 * MT * wm + 2 * half) * COUT + ncol) * 4;
     const uint4 *gbp = gp + ncol * 2 + half;
-    constexpr int MG = G::MG;
+    constexpr int MG = G::MG, NPH = G::NPHASE;
+    constexpr int NV = MG * NT * 16;          // z values per lane and phase
+    constexpr int NS = MG * NT * 8;           // packed splits (two values each) per lane and phase
+    constexpr int NSLOT = (COUT / 16) * MG * NT * 3;   // MFMAs of one phase's GEMM
+    // value v of phase p lives in acc[p * MG + v / (16 * NT)][(v / 16) % NT][v % 16]
+    auto split_z = [&](int p, int sidx) {
+        const int mt = sidx / (8 * NT), nt = (sidx / 8) % NT, r = (sidx % 8) * 2;   // registers r, r + 1: neighbouring rows
+        unsigned hi, lo;
+        split2_f16(acc[p * MG + mt][nt][r], acc[p * MG + mt][nt][r + 1], hi, lo);
+        char *zh = smem + (p & 1) * 2 * G::PLANE_Z, *zl = zh + G::PLANE_Z;
+        const int off = (32 * MG * wm + 32 * mt + acc_row(r, half)) * G::ZSB + (ncol + 32 * nt) * 2;
+        *reinterpret_cast<unsigned short *>(zh + off) = static_cast<unsigned short>(hi);
+        *reinterpret_cast<unsigned short *>(zl + off) = static_cast<unsigned short>(lo);
+        *reinterpret_cast<unsigned short *>(zh + off + G::ZSB) = static_cast<unsigned short>(hi >> 16);
+        *reinterpret_cast<unsigned short *>(zl + off + G::ZSB) = static_cast<unsigned short>(lo >> 16);
+    };
+    // sigmoid in two halves (each ends in a transcendental, whose latency the other half's covers)
+    auto sig_a = [&](int p, int v) {
+        f32x16 &a = acc[p * MG + v / (16 * NT)][(v / 16) % NT];
+        a[v % 16] = __builtin_amdgcn_exp2f(a[v % 16] * -1.4426950408889634f);
+    };
+    auto sig_b = [&](int p, int v) {
+        f32x16 &a = acc[p * MG + v / (16 * NT)][(v / 16) % NT];
+        a[v % 16] = __builtin_amdgcn_rcpf(1.0f + a[v % 16]);
+    };
+    float gsc[NT], gbias[NT];
 #pragma unroll
-    for (int m0 = 0; m0 < MT; m0 += MG) {
-        __syncthreads();                 // readers of the planes (main loop / previous phase) are done
+    for (int nt = 0; nt < NT; ++nt) {
+        gsc[nt] = g_s[ncol + 32 * nt];
+        gbias[nt] = gb[ncol + 32 * nt];
+    }
+    __syncthreads();                     // every wave is done reading the input planes
+    SPLIT_TICK(5);
 #pragma unroll
-        for (int mt = 0; mt < MG; ++mt)
+    for (int sidx = 0; sidx < NS; ++sidx) split_z(0, sidx);
+    __syncthreads();
+    SPLIT_TICK(6);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {     // registers r, r + 1 are neighbouring rows: packed converts
-                    unsigned hi, lo;
-                    split2_f16(acc[m0 + mt][nt][r], acc[m0 + mt][nt][r + 1], hi, lo);
-                    const int off = (32 * MG * wm + 32 * mt + acc_row(r, half)) * G::ZSB + (ncol + 32 * nt) * 2;
-                    *reinterpret_cast<unsigned short *>(plane_h + off) = static_cast<unsigned short>(hi);
-                    *reinterpret_cast<unsigned short *>(plane_l + off) = static_cast<unsigned short>(lo);
-                    *reinterpret_cast<unsigned short *>(plane_h + off + G::ZSB) = static_cast<unsigned short>(hi >> 16);
-                    *reinterpret_cast<unsigned short *>(plane_l + off + G::ZSB) = static_cast<unsigned short>(lo >> 16);
-                }
-        __syncthreads();
+    for (int p = 0; p < NPH; ++p) {
         f32x16 lin[MG][NT];
 #pragma unroll
         for (int mt = 0; mt < MG; ++mt)
@@ -291,27 +353,52 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         const char *zh[MG], *zl[MG];
 #pragma unroll
         for (int mt = 0; mt < MG; ++mt) {
-            const int off = (32 * MG * wm + 32 * mt + col32) * G::ZSB + 16 * half;
-            zh[mt] = plane_h + off;
-            zl[mt] = plane_l + off;
+            const int off = (p & 1) * 2 * G::PLANE_Z + (32 * MG * wm + 32 * mt + col32) * G::ZSB + 16 * half;
+            zh[mt] = smem + off;
+            zl[mt] = smem + off + G::PLANE_Z;
         }
-        split_gemm<MG, NT, COUT / 16>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; });
+        split_gemm<MG, NT, COUT / 16>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; }, [&](int j) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float gsc = g_s[ncol + 32 * nt], bias = gb[ncol + 32 * nt];
+            for (int v = 0; v < NV; ++v) {
+                if (v * NSLOT / NV == j) sig_a(p, v);
+                if (v * NSLOT / NV == j - 1) sig_b(p, v);
+            }
+            if (p + 1 < NPH) {
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx)
+                    if (sidx * NSLOT / NS == j) split_z(p + 1, sidx);
+            }
+        });
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (v * NSLOT / NV == NSLOT - 1) sig_b(p, v);
+        SPLIT_TICK(7);
+        // the next phase's planes are complete, and this phase's are free to be overwritten after it
+        if (p + 1 < NPH) __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MG; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float o0 = fmaf(lin[mt][nt][r], gsc, bias) * sigmoidf_fast(acc[m0 + mt][nt][r]);
-                    const float o1 = fmaf(lin[mt][nt][r + 1], gsc, bias) * sigmoidf_fast(acc[m0 + mt][nt][r + 1]);
+                    const float o0 = fmaf(lin[mt][nt][r], gsc[nt], gbias[nt]) * acc[p * MG + mt][nt][r];
+                    const float o1 = fmaf(lin[mt][nt][r + 1], gsc[nt], gbias[nt]) * acc[p * MG + mt][nt][r + 1];
                     // acc_row(r, half) / 2 = (r & 3) / 2 + 4 * (r >> 2) + 2 * half for even r
-                    const int yoff = ((16 * (m0 + mt) + (r & 3) / 2 + 4 * (r >> 2)) * COUT + 32 * nt) * 4;
+                    const int yoff = ((16 * (p * MG + mt) + (r & 3) / 2 + 4 * (r >> 2)) * COUT + 32 * nt) * 4;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0 + o1), yrsrc,
                                                           ybase + yoff, 0, 0);
                 }
-        }
+        SPLIT_TICK(8);
     }
+#ifdef SPLIT_TIMING
+    if (tid == 0) {
+        constexpr int layer = W == 64 ? 0 : W == 32 ? 1 : W == 16 ? 2 : W == 8 ? 3 : W == 4 ? 4 : 5;
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_split_ticks[layer][i], tick_acc[i]);
+        atomicAdd(&g_split_ticks[layer][9], 1ull);
+        atomicMin(&g_split_ticks[layer][10], tick_first);
+        atomicMax(&g_split_ticks[layer][11], tick_last);
+    }
+#endif
 }
 
 

@@ -1053,3 +1053,15 @@ int sedmi_crnn_forward_f32(const sedmi_crnn *m, const float *feats, int64_t n_cl
 }
 
 }  // extern "C"
+
+#ifdef SPLIT_TIMING
+// diagnostic build only: copies out and clears the per-section tick sums of conv_split_kernel
+extern "C" int sedmi_debug_split_ticks(unsigned long long *out72) {
+    SEDMI_CHECK_HIP(hipDeviceSynchronize());
+    SEDMI_CHECK_HIP(hipMemcpyFromSymbol(out72, HIP_SYMBOL(g_split_ticks), sizeof(unsigned long long) * 72));
+    unsigned long long init[72] = {};
+    for (int l = 0; l < 6; ++l) init[l * 12 + 10] = ~0ull;
+    SEDMI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_split_ticks), init, sizeof(init)));
+    return SEDMI_OK;
+}
+#endif
