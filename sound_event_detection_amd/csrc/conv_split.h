@@ -18,6 +18,9 @@
 #ifndef SPLIT_BDIST
 #define SPLIT_BDIST 1
 #endif
+#ifndef SPLIT_GLU_BDIST
+#define SPLIT_GLU_BDIST 1     // same, for the GEMM of the GLU phases
+#endif
 #ifdef SPLIT_TIMING
 // diagnostic build only: per-layer sums of s_memtime ticks spent in each section of conv_split_kernel
 // (wave 0 of every workgroup), read back through sedmi_debug_split_ticks
@@ -107,6 +110,14 @@ __device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int 
 // hook(slot) runs after every MFMA (slot = running MFMA index, slot0 + 3 * (mt * NT + nt) + 0..2) and is
 // pinned there: vector-ALU work issued between the MFMAs of a wave overlaps with the MFMAs of the other
 // wave on the SIMD, while a long run of pure vector work next to a long run of MFMAs does not.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of
+// the wave has been acknowledged, which puts an HBM write latency into each GLU phase.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct SplitNoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -150,12 +161,12 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
 // before the MFMAs of step i issue (their latency is several hundred cycles).
 // a_off(i) = LDS byte offset of step i relative to ah/al; N = columns of the packed weight matrix
 // (B advances by 4*N uint4 per k-step: 2 planes x N columns x 32 B).
-template <int MT, int NT, int NSTEPS, typename AOff, typename Hook = SplitNoHook>
+template <int MT, int NT, int NSTEPS, int D = SPLIT_BDIST, typename AOff, typename Hook = SplitNoHook>
 __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
                                            const uint4 *b, int N, AOff a_off, Hook hook = Hook()) {
     const int BS = N * 4, n2 = N * 2;
     // weights are requested SPLIT_BDIST k-steps ahead of their use, through a ring of register buffers
-    constexpr int D = SPLIT_BDIST, NB = D + 1;
+    constexpr int NB = D + 1;
     SplitB<NT> bb[NB];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             zh[mt] = smem + off;
             zl[mt] = smem + off + G::PLANE_Z;
         }
-        split_gemm<MG, NT, COUT / 16>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; }, [&](int j) {
+        split_gemm<MG, NT, COUT / 16, SPLIT_GLU_BDIST>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; }, [&](int j) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 if (v * NSLOT / NV == j) sig_a(p, v);
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             if (v * NSLOT / NV == NSLOT - 1) sig_b(p, v);
         SPLIT_TICK(7);
         // the next phase's planes are complete, and this phase's are free to be overwritten after it
-        if (p + 1 < NPH) __syncthreads();
+        if (p + 1 < NPH) lds_barrier();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

@@ -163,6 +163,95 @@ __global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__
     }
 }
 
+// Block 0 on the f16 matrix cores (split-f16, as conv_split_kernel): out[32 rows][32 positions] =
+// Wfold[32][9 taps] . patches[9][32], one MFMA triple per member of the 2x2 pooling window, all four
+// members of a pooled position in the same lane so that the pooling is a lane-local sum.
+// The 32 rows are ordered so that a lane's 16 accumulator registers hold z (registers 0-7) and lin
+// (8-15) of the SAME eight channels 8*half .. 8*half+7: no cross-lane traffic for the gate.
+// z rows carry -log2(e) * z * 2^Sz (so sigmoid = 1 / (1 + exp2(acc * 2^-Sz))), lin rows 0.25 * lin * 2^Sl;
+// the biases enter as the initial accumulator.  Lanes 32-63 supply contraction indices 8-15, of which
+// only tap 8 is real: they read it through their own base address and read zeros for the rest.
+#ifndef C0_TH_V
+#define C0_TH_V 8
+#endif
+#ifndef C0_OCC
+#define C0_OCC 4
+#endif
+constexpr int C0_TH = C0_TH_V;                   // pooled rows per workgroup
+constexpr int C0_HO = 4;                    // LDS column of input column 0 (keeps the float4 stores aligned)
+constexpr int C0_RS = 128 + 2 * C0_HO;      // LDS row stride in floats
+constexpr int C0_ROWS = 2 * C0_TH + 2;      // staged input rows
+__global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *__restrict__ x,
+                                                          const uint4 *__restrict__ wpk,     // [2 planes][32 rows][16] f16
+                                                          const float *__restrict__ bias32,  // [32] scaled row biases
+                                                          float zscale, float lscale,        // 2^-Sz, 2^-Sl
+                                                          float *__restrict__ y, int T, int Tp, int tiles_per_clip) {
+    // x [clip][T][128], y [clip][Tp][64][16]
+    __shared__ __attribute__((aligned(16))) float lds[(C0_ROWS + 4) * C0_RS];   // + 4 rows of zeros
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const long clip = blockIdx.x / tiles_per_clip;
+    const int h20 = static_cast<int>(blockIdx.x % tiles_per_clip) * C0_TH;
+    const float *xc = x + clip * static_cast<long>(T) * 128;
+    for (int i = tid; i < C0_ROWS * 32; i += 256) {
+        const int rr = i >> 5, c4 = (i & 31) * 4, hr = 2 * h20 - 1 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hr >= 0 && hr < T) v = *reinterpret_cast<const float4 *>(xc + static_cast<long>(hr) * 128 + c4);
+        *reinterpret_cast<float4 *>(&lds[rr * C0_RS + C0_HO + c4]) = v;
+    }
+    for (int i = tid; i < C0_ROWS * 2; i += 256) lds[(i >> 1) * C0_RS + ((i & 1) ? C0_HO + 128 : C0_HO - 1)] = 0.f;
+    for (int i = tid; i < 4 * C0_RS; i += 256) lds[C0_ROWS * C0_RS + i] = 0.f;
+
+    const uint4 wh = wpk[col32 * 2 + half], wl = wpk[64 + col32 * 2 + half];
+    const f16x8 a_hi = __builtin_bit_cast(f16x8, wh), a_lo = __builtin_bit_cast(f16x8, wl);
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = bias32[acc_row(r, half)];
+    __syncthreads();
+
+    // groups of 32 pooled positions (half a pooled row), dealt round-robin to the waves
+#pragma unroll 1
+    for (int gi = wave; gi < 2 * C0_TH; gi += 4) {
+        const int prow = gi >> 1, w2 = 32 * (gi & 1) + col32, h2 = h20 + prow;
+        // patch[r][c] of this pooled position = lds[(2 * prow + r) * RS + HO - 1 + 2 * w2 + c]
+        const int pb = (2 * prow) * C0_RS + C0_HO - 1 + 2 * w2;
+        const float *p0 = lds + (half ? pb + 2 * C0_RS + 2 : pb);        // index 0: tap 0 / tap 8
+        const float *pz = lds + (half ? C0_ROWS * C0_RS : pb);          // indices 1..7: taps 1..7 / zeros
+        f32x16 acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int dy = p >> 1, dx = p & 1;
+            float v[8];
+            v[0] = p0[dy * C0_RS + dx];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) v[j] = pz[(dy + j / 3) * C0_RS + dx + j % 3];
+            unsigned bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2_f16(v[2 * j], v[2 * j + 1], bh[j], bl[j]);
+            const f16x8 b_hi = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const f16x8 b_lo = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, cinit, 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[p], 0, 0, 0);
+        }
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[p][r] * zscale));
+                o[r] = fmaf(acc[p][r + 8], gate, o[r]);
+            }
+        if (h2 < Tp) {
+            float4 *dst = reinterpret_cast<float4 *>(y + ((clip * Tp + h2) * 64 + w2) * 16 + 8 * half);
+            dst[0] = make_float4(o[0] * lscale, o[1] * lscale, o[2] * lscale, o[3] * lscale);
+            dst[1] = make_float4(o[4] * lscale, o[5] * lscale, o[6] * lscale, o[7] * lscale);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // blocks 1..6: implicit-GEMM conv + BN + GLU + pool(1,2)
 // ---------------------------------------------------------------------------
@@ -608,6 +697,9 @@ constexpr int kCnnChunk = 512;      // clips per pass through the conv stack (bo
 struct sedmi_crnn {
     int n_class = 0, device = 0, num_cus = 0;
     Conv0Params *d_c0 = nullptr;
+    uint16_t *d_c0s = nullptr;         // block 0 for the matrix cores: split-f16 folded weights [2][32][16]
+    float *d_c0bias = nullptr;         // and the scaled row biases
+    float c0_zscale = 1.f, c0_lscale = 1.f;
     float *d_wp[SEDMI_CRNN_LAYERS] = {};   // packed conv weights (blocks 1..6)
     float *d_s[SEDMI_CRNN_LAYERS] = {}, *d_t[SEDMI_CRNN_LAYERS] = {};
     float *d_gp[SEDMI_CRNN_LAYERS] = {}, *d_gb[SEDMI_CRNN_LAYERS] = {};
@@ -709,7 +801,14 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
             const double pos = static_cast<double>(nc) * (2.0 * Tp) * 128;
             sedmi::ProfileScope prof("conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
                                      4.0 * nc * (static_cast<double>(T) * 128 + Tp * 64.0 * 16));
-            hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
+            if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
+                const int tiles = static_cast<int>(sedmi::ceil_div(Tp, C0_TH));
+                hipLaunchKernelGGL(conv0_split_kernel, dim3(static_cast<unsigned>(nc * tiles)), dim3(256), 0, s, x,
+                                   reinterpret_cast<const uint4 *>(m->d_c0s), m->d_c0bias, m->c0_zscale, m->c0_lscale,
+                                   actA, T, Tp, tiles);
+            } else {
+                hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
+            }
         }
         SEDMI_CHECK_LAUNCH();
         int rc;
@@ -858,6 +957,31 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
         if (hipMalloc(reinterpret_cast<void **>(&m->d_c0), sizeof(p)) != hipSuccess ||
             hipMemcpy(m->d_c0, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess)
             return fail(sedmi::set_error(SEDMI_EHIP, "uploading block 0 parameters failed"));
+        // matrix-core variant: row acc_row(r, half) of the folded 32 x 9 matrix is z (r < 8) or lin (r >= 8) of
+        // channel 8 * half + (r & 7); z rows times -log2(e), lin rows times the pooling factor 1/4
+        const double kNegLog2e = -1.4426950408889634;
+        float rows[32][9], rbias[32];
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int i = acc_row(r, h), c = 8 * h + (r & 7);
+                for (int k = 0; k < 9; ++k)
+                    rows[i][k] = static_cast<float>(r < 8 ? kNegLog2e * p.wz[c][k] : 0.25 * p.wl[c][k]);
+                rbias[i] = static_cast<float>(r < 8 ? kNegLog2e * p.t[c] : 0.25 * p.b2[c]);
+            }
+        auto is_z = [](int i) { return (i & 16) == 0; };   // acc_row(r, h) < 16 exactly for r < 8
+        float zw[16 * 9], lw[16 * 9];
+        int nz = 0, nl = 0;
+        for (int i = 0; i < 32; ++i)
+            for (int k = 0; k < 9; ++k) (is_z(i) ? zw[nz++] : lw[nl++]) = rows[i][k];
+        const int Sz = split_scale_exp(zw, nz), Sl = split_scale_exp(lw, nl);
+        auto c0s = pack_split(1, 32, 0, [&](int, int k16, int n) {
+            return k16 < 9 ? std::ldexp(rows[n][k16], is_z(n) ? Sz : Sl) : 0.f;
+        });
+        std::vector<float> c0bias(32);
+        for (int i = 0; i < 32; ++i) c0bias[i] = std::ldexp(rbias[i], is_z(i) ? Sz : Sl);
+        m->c0_zscale = std::ldexp(1.0f, -Sz);
+        m->c0_lscale = std::ldexp(1.0f, -Sl);
+        if ((rc = sedmi::upload(&m->d_c0s, c0s)) || (rc = sedmi::upload(&m->d_c0bias, c0bias))) return fail(rc);
     }
     for (int i = 1; i < SEDMI_CRNN_LAYERS; ++i) {
         const int ci = kFilters[i - 1], co = kFilters[i];
@@ -955,6 +1079,8 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
 int sedmi_crnn_destroy(sedmi_crnn *m) {
     if (!m) return SEDMI_OK;
     (void)hipFree(m->d_c0);
+    (void)hipFree(m->d_c0s);
+    (void)hipFree(m->d_c0bias);
     for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
         (void)hipFree(m->d_wp[i]); (void)hipFree(m->d_s[i]); (void)hipFree(m->d_t[i]);
         (void)hipFree(m->d_gp[i]); (void)hipFree(m->d_gb[i]);

@@ -14,7 +14,7 @@ __device__ __forceinline__ float tanhf_fast(float x) {
 }
 
 // row of accumulator register `reg` inside a 32x32 MFMA tile (column = lane & 31)
-__device__ __forceinline__ constexpr int acc_row(int reg, int half) {
+__host__ __device__ __forceinline__ constexpr int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
