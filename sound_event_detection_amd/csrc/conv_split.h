@@ -415,11 +415,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
 
 // C[M][N] = A[M][K] . B + bias with the same split-f16 arithmetic (GRU input projections).
 // A row-major f32; B packed [K/16][2][N][16] f16 (hi, lo) pre-scaled by 2^S; out = acc * oscale + bias.
-// A workgroup owns 128 rows: it stages them ONCE as hi/lo planes for the whole K, then walks the N
-// columns 64*WN at a time (2 x WN waves; WN = 4 where the planes leave room for one workgroup per
+// A workgroup owns 128 rows at a time: it stages them ONCE as hi/lo planes for the whole K, then walks
+// the N columns 64*WN at a time (2 x WN waves; WN = 4 where the planes leave room for one workgroup per
 // CU only, so that it still brings two waves per SIMD) with no barrier in that loop, so the stores of one
 // column block drain while the next block's MFMAs run.  The output is 3-6x the input here, so the
-// kernel is bounded by the rate at which C can be written.
+// kernel is bounded by the rate at which C can be written.  Workgroups are persistent over row tiles
+// (tile, tile + gridDim.x, ...) and request the next tile's rows into registers before they start on
+// the current one, so that the only exposed input latency is the first tile's.
 template <int N, int K, int WN>
 __global__ __launch_bounds__(128 * WN, (K <= 128 ? 2 : 1)) void linear_split_kernel(const float *__restrict__ A,
                                                                              const uint4 *__restrict__ bpk,
@@ -427,34 +429,36 @@ __global__ __launch_bounds__(128 * WN, (K <= 128 ? 2 : 1)) void linear_split_ker
                                                                              float *__restrict__ C, long M) {
     constexpr int PSB = K * 2 + 16, PLANE = 128 * PSB;
     constexpr int NTHR = 128 * WN, NB = 64 * WN;
-    static_assert(N % NB == 0 && K % 64 == 0, "unsupported linear geometry");
+    static_assert(N % NB == 0 && K % 64 == 0 && (128 * (K / 4)) % NTHR == 0, "unsupported linear geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = static_cast<long>(blockIdx.x) * 128;
-    constexpr int KC = 64, NLD = 128 * (KC / 4) / NTHR;    // staged 64 columns at a time
-#pragma unroll 1
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        float4 v[NLD];
+    const long n_tiles = (M + 127) / 128;
+    constexpr int NLD = 128 * (K / 4) / NTHR;              // float4 per thread and tile
+    // rows of a tile are addressed through buffer descriptors that end at the matrix' last row: loads past
+    // it return zero and stores past it are dropped.  The range check covers the per-lane offset only, not
+    // the scalar offset operand, so everything that selects a ROW has to be in the per-lane offset.
+    // (the builtin's result is converted as a whole: indexing its integer vector type element by element
+    // and bit-casting each element to float compiles to a one-dword load of element 0)
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 v[NLD];
+    const int ld_off = ((tid / (K / 4)) * K + (tid % (K / 4)) * 4) * 4;
+    static_assert(NTHR % (K / 4) == 0, "a thread keeps its column over the tile's loads");
+    auto tile_rows_bytes = [&](long m0, int row_bytes) {
+        const long rows = M - m0 < 128 ? M - m0 : 128;
+        return static_cast<int>(rows) * row_bytes;
+    };
+    auto load_tile = [&](long tile) {
+        const long m0 = tile * 128;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A) + m0 * K, 0,
+                                                                            tile_rows_bytes(m0, K * 4), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + NTHR * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) v[j] = *reinterpret_cast<const float4 *>(A + (m0 + r) * K + k0 + c);
-        }
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + NTHR * j, r = i / (KC / 4), c = (i - r * (KC / 4)) * 4;
-            uint2 hi, lo;
-            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
-            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
-            *reinterpret_cast<uint2 *>(plane_h + r * PSB + (k0 + c) * 2) = hi;
-            *reinterpret_cast<uint2 *>(plane_l + r * PSB + (k0 + c) * 2) = lo;
-        }
-    }
-    __syncthreads();
+        for (int j = 0; j < NLD; ++j)
+            v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs, ld_off + j * (NTHR / (K / 4)) * K * 4, 0, 0));
+    };
     const char *ah[2], *al[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -462,27 +466,50 @@ __global__ __launch_bounds__(128 * WN, (K <= 128 ? 2 : 1)) void linear_split_ker
         ah[mt] = plane_h + off;
         al[mt] = plane_l + off;
     }
+    if (blockIdx.x < n_tiles) load_tile(blockIdx.x);
 #pragma unroll 1
-    for (int nb = 0; nb < N / NB; ++nb) {
-        const int ncol = nb * NB + wn * 64 + col32;
-        f32x16 acc[2][2];
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long m0 = tile * 128;
+        if (tile != blockIdx.x) lds_barrier();             // every wave is done with the previous tile's planes
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-        split_gemm<2, 2, K / 16>(acc, ah, al, bpk + ncol * 2 + half, N, [](int i) { return i * 32; });
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float bv = bias[ncol + 32 * nt];
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + NTHR * j, r = i / (K / 4), c = (i - r * (K / 4)) * 4;
+            uint2 hi, lo;
+            split2_f16(v[j][0], v[j][1], hi.x, lo.x);
+            split2_f16(v[j][2], v[j][3], hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(plane_h + r * PSB + c * 2) = hi;
+            *reinterpret_cast<uint2 *>(plane_l + r * PSB + c * 2) = lo;
+        }
+        lds_barrier();
+        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C + m0 * N, 0, tile_rows_bytes(m0, N * 4), 0x00020000);
+        const int st_off = ((64 * wm + 4 * half) * N + wn * 64 + col32) * 4;
+#pragma unroll 1
+        for (int nb = 0; nb < N / NB; ++nb) {
+            const int ncol = nb * NB + wn * 64 + col32;
+            // the column block is folded into the lane offset: with a loop-invariant base the compiler keeps
+            // all 64 store offsets of a lane in registers across the loop, which spills
+            int so = st_off + nb * NB * 4;
+            asm volatile("" : "+v"(so));
+            f32x16 acc[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + 64 * wm + 32 * mt + acc_row(r, half);
-                    if (row < M) C[row * N + ncol + 32 * nt] = fmaf(acc[mt][nt][r], oscale, bv);
-                }
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            split_gemm<2, 2, K / 16>(acc, ah, al, bpk + ncol * 2 + half, N, [](int i) { return i * 32; });
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bv = bias[ncol + 32 * nt];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)       // row 64 wm + 32 mt + acc_row(r, half), column ncol + 32 nt
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __builtin_bit_cast(unsigned, fmaf(acc[mt][nt][r], oscale, bv)), crs,
+                            so + ((32 * mt + acc_row(r, 0)) * N + 32 * nt) * 4, 0, 0);
+            }
         }
     }
 }

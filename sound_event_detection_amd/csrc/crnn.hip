@@ -844,7 +844,9 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj_split<128>" : "gru_input_proj_split<256>", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
-            const dim3 grid(static_cast<unsigned>(sedmi::ceil_div(rows, 128)));
+            // persistent workgroups: as many as fit on the chip at once (two per CU at K = 128, one at K = 256)
+            const long row_tiles = sedmi::ceil_div(rows, 128);
+            const dim3 grid(static_cast<unsigned>(std::min<long>(row_tiles, static_cast<long>(m->num_cus) * (layer == 0 ? 2 : 1))));
             const uint4 *wsp = reinterpret_cast<const uint4 *>(m->d_wihs[layer]);
             if (layer == 0) {
                 const size_t lds2 = 2 * 128 * (128 * 2 + 16);

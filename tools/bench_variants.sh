@@ -7,7 +7,7 @@ for lib in "$@"; do
 import json
 d = json.load(open("gpurun_out/bv.json"))
 print(round(d["value"]), round(d["ms_per_step"], 2))
-for k in d["kernels"][:10]:
+for k in d["kernels"][:13]:
     print("   ", k["name"], round(k["ms_total"] / k["launches"] * 1e3, 1), "us")
 PY
 done
