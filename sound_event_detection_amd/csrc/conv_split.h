@@ -340,12 +340,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         f32x16 &a = acc[p * MG + v / (16 * NT)][(v / 16) % NT];
         a[v % 16] = __builtin_amdgcn_rcpf(1.0f + a[v % 16]);
     };
-    float gsc[NT], gbias[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        gsc[nt] = g_s[ncol + 32 * nt];
-        gbias[nt] = gb[ncol + 32 * nt];
-    }
     __syncthreads();                     // every wave is done reading the input planes
     SPLIT_TICK(5);
 #pragma unroll
@@ -368,7 +362,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             zh[mt] = smem + off;
             zl[mt] = smem + off + G::PLANE_Z;
         }
+        // GLU scale and bias of this lane's columns: requested half way through the GEMM (late enough not to
+        // add to its register peak, early enough for the rest of it to cover the latency)
+        float gsc[NT], gbias[NT];
         split_gemm<MG, NT, COUT / 16, SPLIT_GLU_BDIST>(lin, zh, zl, gbp, COUT, [](int i) { return i * 32; }, [&](int j) {
+            if (j == NSLOT / 2) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    gsc[nt] = g_s[ncol + 32 * nt];
+                    gbias[nt] = gb[ncol + 32 * nt];
+                }
+            }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 if (v * NSLOT / NV == j) sig_a(p, v);
