@@ -510,12 +510,21 @@ __global__ __launch_bounds__(256, 1) void gru_kernel(
     }
 }
 
-// The same recurrence with the h . W_hh^T product in split-f16 arithmetic: W_hh sits in registers as
-// f16 (hi, lo) B fragments (192 VGPRs, as many as the f32 form), h goes through LDS as two f16 planes,
-// and a step costs 72 f16 MFMAs (2304 issue cycles) instead of 192 f32 MFMAs (12288).
+// The same recurrence with the h . W_hh^T product in split-f16 arithmetic on v_mfma_f32_16x16x32_f16.
+// Eight waves, two per SIMD: wave w owns the r, z, n columns of hidden units 16 w .. 16 w + 15 for all 32
+// clips (two 16-row tiles), so the gate arithmetic is lane-local on accumulator registers, W_hh sits in
+// registers as f16 (hi, lo) B fragments (96 VGPRs per wave), and h goes through LDS as two f16 planes,
+// double buffered, one barrier per step.  A step costs each wave 72 MFMAs of 16 cycles and ~220
+// vector-ALU instructions of gate arithmetic; a wave cannot overlap its own vector work with its own
+// MFMAs, but the two waves of a SIMD overlap each other's (four waves of twice the size, one per SIMD:
+// 1.19 instead of 0.96 ms per layer at 4096 clips).  What bounds it now is reading gi: 3.1 GB per layer in
+// 64-byte pieces, 3.3 TB/s.  Running the two waves of a SIMD deliberately out of phase (the two 16-clip
+// tiles are independent recurrences, so one wave can be in its gates while the other is in its chain,
+// at the price of a second barrier per step) changes nothing for that reason.
 constexpr int GRU_PSB = GRU_H * 2 + 16;      // bytes per clip row of one h plane
+using f32x4v = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(256, 1) void gru_split_kernel(
+__global__ __launch_bounds__(512, 1) void gru_split_kernel(
     const float *__restrict__ gi,      // [clip][T][2][3H]
     const uint4 *__restrict__ whh,     // packed split [2][H/16][2 planes][3H][16] f16, pre-scaled by 2^S
     float whh_oscale,                  // 2^-S
@@ -524,78 +533,108 @@ __global__ __launch_bounds__(256, 1) void gru_split_kernel(
     long n_clips, int T) {
     __shared__ __attribute__((aligned(16))) char hs[2][2][GRU_NB * GRU_PSB];     // [buffer][plane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, col32 = lane & 31;
+    const int n16 = lane & 15, kg = lane >> 4;        // column (A: row) within a 16-wide tile; k-group / row group
     const int dir = blockIdx.y;
     const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;
-    const int j = 32 * wave + col32;                  // hidden unit owned by this lane
+    const int j = 16 * wave + n16;                    // hidden unit owned by this lane
 
-    f16x8 wh[3][GRU_H / 16], wl[3][GRU_H / 16];
+    // B fragment of k-step ks (32 indices): this lane's 8 indices 32 ks + 8 kg .. + 7 of column g * H + j
+    f16x8 wh[3][GRU_H / 32], wl[3][GRU_H / 32];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int ks = 0; ks < GRU_H / 16; ++ks) {
-            const uint4 *p = whh + ((static_cast<long>(dir) * (GRU_H / 16) + ks) * 2 * (3 * GRU_H) + g * GRU_H + j) * 2 + half;
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            const int ks16 = 2 * ks + (kg >> 1);
+            const uint4 *p = whh + ((static_cast<long>(dir) * (GRU_H / 16) + ks16) * 2 * (3 * GRU_H) + g * GRU_H + j) * 2 + (kg & 1);
             wh[g][ks] = __builtin_bit_cast(f16x8, p[0]);
             wl[g][ks] = __builtin_bit_cast(f16x8, p[2 * 3 * GRU_H]);
         }
     const float b_hn = bhn[dir * GRU_H + j];
 
-    for (int i = tid; i < static_cast<int>(sizeof(hs) / 4); i += 256) reinterpret_cast<unsigned *>(&hs[0][0][0])[i] = 0u;
-    float hprev[16];
+    for (int i = tid; i < static_cast<int>(sizeof(hs) / 4); i += 512) reinterpret_cast<unsigned *>(&hs[0][0][0])[i] = 0u;
+    // accumulator register i of tile mt is clip 16 mt + 4 kg + i
+    float hprev[2][4];
+    const float *gip[2][4];
+    float *outp[2][4];
+    bool live[2][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hprev[r] = 0.f;
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hprev[mt][i] = 0.f;
+            const long b = b0 + 16 * mt + 4 * kg + i;
+            live[mt][i] = b < n_clips;
+            const long bc = live[mt][i] ? b : n_clips - 1;      // clips past the end of the batch: computed, never stored
+            gip[mt][i] = gi + (bc * T * 2 + dir) * (3 * GRU_H) + j;
+            outp[mt][i] = out + bc * T * (2 * GRU_H) + dir * GRU_H + j;
+        }
     __syncthreads();
 
-    int cur = 0;
-    for (int s = 0; s < T; ++s) {
-        const int t = dir ? T - 1 - s : s;
-        float gir[16], giz[16], gin[16];
+    // h of step s lives in buffer s & 1: a chain of step s reads buffer (s - 1) & 1 while the gates of step s
+    // write the other one, so one barrier per step is enough.
+    auto load_gi = [&](int mt, int s, float (&g)[3][4]) {
+        const long t = dir ? T - 1 - s : s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long b = b0 + acc_row(r, half);
-            gir[r] = giz[r] = gin[r] = 0.f;
-            if (b < n_clips) {
-                const float *p = gi + ((b * T + t) * 2 + dir) * (3 * GRU_H) + j;
-                gir[r] = p[0];
-                giz[r] = p[GRU_H];
-                gin[r] = p[2 * GRU_H];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const float *pr = gip[mt][i] + t * (6 * GRU_H);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[q][i] = pr[q * GRU_H];
         }
-        f32x16 acc[3];
+    };
+    auto chain = [&](int mt, int s, f32x4v (&acc)[3]) {
+        const int rd = (s & 1) ^ 1;
+        // A fragment: row (clip) 16 mt + n16, indices 32 ks + 8 kg .. + 7
+        const char *ah = &hs[rd][0][(16 * mt + n16) * GRU_PSB + 16 * kg], *al = &hs[rd][1][(16 * mt + n16) * GRU_PSB + 16 * kg];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int q = 0; q < 3; ++q) acc[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        f16x8 vah[GRU_H / 32], val[GRU_H / 32];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        const char *ah = &hs[cur][0][col32 * GRU_PSB + 16 * half], *al = &hs[cur][1][col32 * GRU_PSB + 16 * half];
-#pragma unroll
-        for (int ks = 0; ks < GRU_H / 16; ++ks) {
-            const f16x8 vah = *reinterpret_cast<const f16x8 *>(ah + ks * 32);
-            const f16x8 val = *reinterpret_cast<const f16x8 *>(al + ks * 32);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val, wh[g][ks], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah, wl[g][ks], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah, wh[g][ks], acc[g], 0, 0, 0);
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            vah[ks] = *reinterpret_cast<const f16x8 *>(ah + ks * 64);
+            val[ks] = *reinterpret_cast<const f16x8 *>(al + ks * 64);
         }
-        char *nh = &hs[cur ^ 1][0][0], *nl = &hs[cur ^ 1][1][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float rg = sigmoidf_fast(fmaf(acc[0][r], whh_oscale, gir[r]));
-            const float zg = sigmoidf_fast(fmaf(acc[1][r], whh_oscale, giz[r]));
-            const float ng = tanhf_fast(fmaf(rg, fmaf(acc[2][r], whh_oscale, b_hn), gin[r]));
-            const float hn = fmaf(zg, hprev[r] - ng, ng);          // (1 - z) * n + z * h
-            hprev[r] = hn;
-            const int row = acc_row(r, half);
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val[ks], wh[q][ks], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[ks], wl[q][ks], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[ks], wh[q][ks], acc[q], 0, 0, 0);
+        }
+    };
+    auto gates = [&](int mt, int s, const f32x4v (&acc)[3], const float (&g)[3][4]) {
+        const long t = dir ? T - 1 - s : s;
+        char *nh = &hs[s & 1][0][0], *nl = &hs[s & 1][1][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float rg = sigmoidf_fast(fmaf(acc[0][i], whh_oscale, g[0][i]));
+            const float zg = sigmoidf_fast(fmaf(acc[1][i], whh_oscale, g[1][i]));
+            const float ng = tanhf_fast(fmaf(rg, fmaf(acc[2][i], whh_oscale, b_hn), g[2][i]));
+            const float hn = fmaf(zg, hprev[mt][i] - ng, ng);      // (1 - z) * n + z * h
+            hprev[mt][i] = hn;
+            const int row = 16 * mt + 4 * kg + i;
             _Float16 hi, lo;
             split_f16(hn, hi, lo);
             *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
             *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
-            const long b = b0 + row;
-            if (b < n_clips) out[(b * T + t) * (2 * GRU_H) + dir * GRU_H + j] = hn;
+            if (live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;
+        }
+    };
+    // one 16-clip tile at a time: chain, then gates (the next tile's chain of this wave and the other wave's
+    // work cover the latency of the gate arithmetic's tail)
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        float g[2][3][4];
+        load_gi(0, s, g[0]);
+        load_gi(1, s, g[1]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4v acc[3];
+            chain(mt, s, acc);
+            gates(mt, s, acc, g[mt]);
         }
         __syncthreads();
-        cur ^= 1;
     }
 }
 
@@ -874,7 +913,7 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
                                      4.0 * rows * (6.0 * GRU_H + 2.0 * GRU_H));
             const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
             if (m->precision == SEDMI_PRECISION_SPLIT_F16)
-                hipLaunchKernelGGL(gru_split_kernel, ggrid, dim3(256), 0, s, gi,
+                hipLaunchKernelGGL(gru_split_kernel, ggrid, dim3(512), 0, s, gi,
                                    reinterpret_cast<const uint4 *>(m->d_whhs[layer]), m->whh_oscale[layer],
                                    m->d_bhn[layer], outs[layer], n_clips, Tp);
             else
