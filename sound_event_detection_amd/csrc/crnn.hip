@@ -729,7 +729,10 @@ __global__ __launch_bounds__(256, 2) void head_small_kernel(const float *__restr
     }
 }
 
-constexpr int kCnnChunk = 512;      // clips per pass through the conv stack (bounds the scratch)
+#ifndef SEDMI_CNN_CHUNK
+#define SEDMI_CNN_CHUNK 512
+#endif
+constexpr int kCnnChunk = SEDMI_CNN_CHUNK;     // clips per pass through the conv stack (bounds the scratch)
 
 }  // namespace
 
