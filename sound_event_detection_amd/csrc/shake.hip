@@ -14,7 +14,7 @@
 // columns of W_ih are permuted once at model creation instead of moving data.
 //
 // Kernels
-//   shake_conv1_kernel   block 1 conv (5x5, 1 -> 32) + BN + GLU: VALU, weights as LDS broadcasts.
+//   shake_conv1_split_kernel  block 1 conv (5x5, 1 -> 32) + BN + GLU on the matrix cores (K = 25 padded to 32).
 //   conv2d_split_kernel  every other conv (3x3): implicit GEMM on the f16 matrix cores with the
 //                        split-f16 arithmetic of conv_split.h, 8 x 32 position tiles with halo.
 //                        MODE_GLU : BN affine + GLU halving (the two halves of a channel pair sit in
@@ -43,75 +43,91 @@ namespace {
 // ---------------------------------------------------------------------------
 // block 1: 5x5 conv, 1 -> 32 channels, BN affine, GLU halving -> u [B][H][W][16]
 // ---------------------------------------------------------------------------
-struct ShakeConv1Params {
+struct ShakeConv1Params {   // host-side staging of the block's parameters
     float w[32][28];     // [co][25 taps + 3 pad]
     float s[32], t[32];  // z = conv * s + t
 };
 
-__global__ __launch_bounds__(256, 2) void shake_conv1_kernel(const float *__restrict__ x,
-                                                             const ShakeConv1Params *__restrict__ prm,
-                                                             float *__restrict__ u, long n_clips, int H, int W) {
-    __shared__ float4 wsm[32][8];      // [co][0..6] taps, [co][7] = (s, t, 0, 0)
-    {
-        const int co = threadIdx.x >> 3, j = threadIdx.x & 7;
-        float4 v;
-        if (j < 7) v = make_float4(prm->w[co][4 * j], prm->w[co][4 * j + 1], prm->w[co][4 * j + 2], prm->w[co][4 * j + 3]);
-        else v = make_float4(prm->s[co], prm->t[co], 0.f, 0.f);
-        wsm[co][j] = v;
+// On the f16 matrix cores (split-f16): out[32 rows][32 positions] = Wfold[32][32] .
+// patches[32][32] (25 taps, zero-weighted padding), two k-steps of 16.  BatchNorm's scale is folded into
+// the weights, its shift is the initial accumulator.  The 32 rows are ordered so that a lane's 16
+// accumulator registers hold the value half (registers 0-7) and the gate half (8-15) of the SAME eight
+// output channels 8*half .. 8*half+7: the GLU is lane-local.  Gate rows carry -log2(e) * z * 2^Sb
+// (sigmoid = 1 / (1 + exp2(acc * 2^-Sb))), value rows z * 2^Sa.  A lane supplies contraction indices
+// 16 ks + 8 half + 0..7 of its position's 5x5 patch through a per-lane table of LDS offsets; the seven
+// padding indices point at tap 0 (inside the same patch) and meet zero weights.
+constexpr int C1_TR = 4;                     // time rows per workgroup
+constexpr int C1_HO = 4;                     // LDS column of input column 0 (keeps the float4 stores aligned)
+__global__ __launch_bounds__(256, 2) void shake_conv1_split_kernel(const float *__restrict__ x,
+                                                                   const uint4 *__restrict__ wpk,     // [2 ks][2 planes][32 rows][16] f16
+                                                                   const float *__restrict__ bias32,  // [32] scaled row shifts
+                                                                   float ascale, float bscale,        // 2^-Sa, 2^-Sb
+                                                                   float *__restrict__ u, int H, int W, int tiles_per_clip) {
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];   // [C1_TR + 4][W + 2 * C1_HO]
+    const int RS = W + 2 * C1_HO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col32 = lane & 31;
+    const long clip = blockIdx.x / tiles_per_clip;
+    const int y0 = static_cast<int>(blockIdx.x % tiles_per_clip) * C1_TR;
+    const float *xc = x + clip * static_cast<long>(H) * W;
+    const int row_f4 = W / 4;
+    for (int i = tid; i < (C1_TR + 4) * row_f4; i += 256) {
+        const int rr = i / row_f4, c4 = (i - rr * row_f4) * 4, yy = y0 - 2 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yy >= 0 && yy < H) v = *reinterpret_cast<const float4 *>(xc + static_cast<long>(yy) * W + c4);
+        *reinterpret_cast<float4 *>(&c1_lds[rr * RS + C1_HO + c4]) = v;
     }
+    for (int i = tid; i < (C1_TR + 4) * 4; i += 256) {           // two halo columns on either side
+        const int rr = i >> 2, j = i & 3;
+        c1_lds[rr * RS + (j < 2 ? C1_HO - 2 + j : C1_HO + W + j - 2)] = 0.f;
+    }
+    f16x8 a_hi[2], a_lo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_hi[ks] = __builtin_bit_cast(f16x8, wpk[(ks * 2 + 0) * 64 + col32 * 2 + half]);
+        a_lo[ks] = __builtin_bit_cast(f16x8, wpk[(ks * 2 + 1) * 64 + col32 * 2 + half]);
+    }
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = bias32[acc_row(r, half)];
+    // LDS offset (floats, relative to the patch's top-left element) of this lane's 16 contraction indices
+    int toff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * half + j, tap = k < 25 ? k : 0;
+            toff[ks][j] = (tap / 5) * RS + tap % 5;
+        }
     __syncthreads();
-    const int Wh = W / 2;
-    const long total = n_clips * H * Wh;
-    const long idx = blockIdx.x * 256L + threadIdx.x;      // one thread = two adjacent positions
-    if (idx >= total) return;
-    const int xi = static_cast<int>(idx % Wh) * 2;
-    const long rest = idx / Wh;
-    const int yi = static_cast<int>(rest % H);
-    const long b = rest / H;
-    const float *xb = x + b * static_cast<long>(H) * W;
-    float patch[5][6];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int yy = yi - 2 + r;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int xx = xi - 2 + c;
-            patch[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[static_cast<long>(yy) * W + xx] : 0.f;
-        }
-    }
-    float4 *dst = reinterpret_cast<float4 *>(u + ((b * H + yi) * static_cast<long>(W) + xi) * 16);
-    // four output channels per trip of a rolled loop: a fully unrolled channel loop lets the
-    // compiler pull every weight read to the top and spill
+
+    const int groups_per_row = W / 32;
 #pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-        float o[2][4];
+    for (int gi = wave; gi < C1_TR * groups_per_row; gi += 4) {
+        const int rr = gi / groups_per_row, xq = (gi - rr * groups_per_row) * 32 + col32, yy = y0 + rr;
+        // patch[ky][kx] = input (yy - 2 + ky, xq - 2 + kx) = c1_lds[(rr + ky) * RS + C1_HO - 2 + xq + kx]
+        const float *pb = c1_lds + rr * RS + C1_HO - 2 + xq;
+        f32x16 acc = cinit;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            float z[2][2];                    // [GLU half][position]
+        for (int ks = 0; ks < 2; ++ks) {
+            unsigned bh[4], bl[4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const float4 *wr = wsm[4 * g + c4 + 16 * hf];
-                float wv[28];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const float4 q = wr[j];
-                    wv[4 * j] = q.x; wv[4 * j + 1] = q.y; wv[4 * j + 2] = q.z; wv[4 * j + 3] = q.w;
-                }
-                const float4 st = wr[7];
-                float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 25; ++k) {
-                    a0 = fmaf(patch[k / 5][k % 5], wv[k], a0);
-                    a1 = fmaf(patch[k / 5][k % 5 + 1], wv[k], a1);
-                }
-                z[hf][0] = fmaf(a0, st.x, st.y);
-                z[hf][1] = fmaf(a1, st.x, st.y);
-            }
-            o[0][c4] = z[0][0] * sigmoidf_fast(z[1][0]);
-            o[1][c4] = z[0][1] * sigmoidf_fast(z[1][1]);
+            for (int j = 0; j < 4; ++j) split2_f16(pb[toff[ks][2 * j]], pb[toff[ks][2 * j + 1]], bh[j], bl[j]);
+            const f16x8 b_hi = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const f16x8 b_lo = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[ks], b_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[ks], b_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[ks], b_hi, acc, 0, 0, 0);
         }
-        dst[g] = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
-        dst[4 + g] = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            o[r] = acc[r] * ascale * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r + 8] * bscale));
+        if (yy < H) {
+            float4 *dst = reinterpret_cast<float4 *>(u + ((clip * H + yy) * static_cast<long>(W) + xq) * 16 + 8 * half);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 
@@ -826,7 +842,9 @@ struct BlockDev {
 };
 
 struct ShakeCnnDev {
-    ShakeConv1Params *d_c1 = nullptr;
+    uint16_t *d_c1s = nullptr;          // block 1 conv: folded split-f16 weights [2][2][32][16]
+    float *d_c1bias = nullptr;          // and the scaled row shifts
+    float c1_ascale = 1.f, c1_bscale = 1.f;
     BlockDev blk[3];
 };
 
@@ -938,10 +956,12 @@ int run_shake_cnn(const ShakeCnnDev *m, const float *feats, long n, int T, const
         const long nc = std::min<long>(kShakeChunk, n - c0);
         const float *x = feats + c0 * static_cast<long>(T) * 768;
         {
-            const long total = nc * T * 384;
             sedmi::ProfileScope prof("shake_conv1", s, 2.0 * 25 * 32 * nc * T * 768.0, 4.0 * nc * T * 768.0 * 17);
-            hipLaunchKernelGGL(shake_conv1_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(total, 256))), dim3(256), 0,
-                               s, x, m->d_c1, sc.u1, nc, T, 768);
+            const int tiles = static_cast<int>(sedmi::ceil_div(T, C1_TR));
+            const size_t lds = sizeof(float) * (C1_TR + 4) * (768 + 2 * C1_HO);
+            hipLaunchKernelGGL(shake_conv1_split_kernel, dim3(static_cast<unsigned>(nc * tiles)), dim3(256), lds, s, x,
+                               reinterpret_cast<const uint4 *>(m->d_c1s), m->d_c1bias, m->c1_ascale, m->c1_bscale, sc.u1,
+                               T, 768, tiles);
             SEDMI_CHECK_LAUNCH();
         }
         int rc;
@@ -1084,8 +1104,33 @@ int create_shake_cnn(ShakeCnnDev &dev, const sedmi_shake_cnn_weights &c) {
                 p.s[k] = s1[k];
                 p.t[k] = t1[k];
             }
-            SEDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&dev.d_c1), sizeof(p)));
-            SEDMI_CHECK_HIP(hipMemcpy(dev.d_c1, &p, sizeof(p), hipMemcpyHostToDevice));
+            // matrix-core variant: row acc_row(r, half) is the value half (r < 8) or the gate half (r >= 8) of output
+            // channel 8 * half + (r & 7); BatchNorm's scale folded in, gate rows times -log2(e)
+            const double kNegLog2e = -1.4426950408889634;
+            float rows[32][25], rshift[32], aw[16 * 25], bw[16 * 25];
+            int na = 0, nbw = 0;
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, h), k = 8 * h + (r & 7) + (r < 8 ? 0 : 16);
+                    const double f = r < 8 ? 1.0 : kNegLog2e;
+                    for (int tap = 0; tap < 25; ++tap) {
+                        rows[row][tap] = static_cast<float>(f * p.s[k] * p.w[k][tap]);
+                        (r < 8 ? aw[na++] : bw[nbw++]) = rows[row][tap];
+                    }
+                    rshift[row] = static_cast<float>(f * p.t[k]);
+                }
+            auto is_gate = [](int row) { return (row & 16) != 0; };   // acc_row(r, h) >= 16 exactly for r >= 8
+            const int Sa = split_scale_exp(aw, na), Sb = split_scale_exp(bw, nbw);
+            auto c1s = pack_split(2, 32, 0, [&](int ks, int k16, int n) {
+                const int k = 16 * ks + k16;
+                return k < 25 ? std::ldexp(rows[n][k], is_gate(n) ? Sb : Sa) : 0.f;
+            });
+            std::vector<float> c1bias(32);
+            for (int row = 0; row < 32; ++row) c1bias[row] = std::ldexp(rshift[row], is_gate(row) ? Sb : Sa);
+            dev.c1_ascale = std::ldexp(1.0f, -Sa);
+            dev.c1_bscale = std::ldexp(1.0f, -Sb);
+            int rc1;
+            if ((rc1 = sedmi::upload(&dev.d_c1s, c1s)) || (rc1 = sedmi::upload(&dev.d_c1bias, c1bias))) return rc1;
         } else {
             const int cch = ci >= 32 ? 32 : 16, ksp = cch / 16;
             const float *src = c.conv_w[i];
@@ -1123,7 +1168,8 @@ int create_shake_cnn(ShakeCnnDev &dev, const sedmi_shake_cnn_weights &c) {
 }
 
 void free_shake_cnn(ShakeCnnDev &dev) {
-    (void)hipFree(dev.d_c1);
+    (void)hipFree(dev.d_c1s);
+    (void)hipFree(dev.d_c1bias);
     for (auto &b : dev.blk) {
         (void)hipFree(b.wa); (void)hipFree(b.wb); (void)hipFree(b.es_a); (void)hipFree(b.et_a);
         (void)hipFree(b.es_b); (void)hipFree(b.et_b); (void)hipFree(b.s2); (void)hipFree(b.t2);
