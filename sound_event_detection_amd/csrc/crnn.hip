@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <type_traits>
 
 namespace {
 
@@ -638,6 +639,14 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     }
 }
 
+// Orders one wave's LDS traffic (DS operations of a wave execute in issue order: the compiler only has to
+// keep that order).
+__device__ __forceinline__ void wave_fence_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------
 // strong head: probs = sigmoid(x . Wd^T + bd), x [rows][256]
 // ---------------------------------------------------------------------------
@@ -672,59 +681,90 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
     }
 }
 
-// The same head for n_cls <= 32 (every configuration the reference trains): the 64 rows of a block
-// are fetched with 16 float4 loads per thread that are all in flight together, rows sit in LDS at a
-// 260-float stride (ds_read_b128 by 16 lanes sweeps all banks once), the weights sit in LDS too and
-// are read as broadcasts; a thread owns one row and every fourth class.
-constexpr int HEAD_XS = HEAD_K + 4;
+// The same head for n_cls <= 32 (every configuration the reference trains) on the f32 matrix instruction
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain).  A wave is on its own: it walks over 32-row tiles,
+// stages a quarter of a tile (32 rows x 64 features) at a time in its private LDS region with fully
+// coalesced loads, requested one quarter ahead into registers, and keeps the whole weight matrix as B
+// operands in registers (lane = class: 128 VGPRs).  The contraction order is permuted so that one 16-byte
+// LDS read feeds four MFMAs: in MFMA i of step j lanes 0-31 carry feature 8 j + i, lanes 32-63 feature
+// 8 j + 4 + i.
 constexpr int HEAD_MAX_SMALL = 32;
+constexpr int HEAD_NQ = 4;                   // staged pieces per tile
+constexpr int HEAD_KQ = HEAD_K / HEAD_NQ;    // features per piece
+constexpr int HEAD_XS = HEAD_KQ + 4;         // LDS row stride (floats): conflict-free ds_read_b128 down a column of rows
 
 __global__ __launch_bounds__(256, 2) void head_small_kernel(const float *__restrict__ x, const float *__restrict__ wd,
                                                             const float *__restrict__ bd, float *__restrict__ probs,
                                                             long n_rows, int n_cls) {
-    extern __shared__ __attribute__((aligned(16))) float head_lds[];
-    float *xs = head_lds;                              // [64][HEAD_XS]
-    float *ws = head_lds + HEAD_ROWS * HEAD_XS;        // [n_cls][HEAD_K]
-    const int tid = threadIdx.x;
-    const long r0 = static_cast<long>(blockIdx.x) * HEAD_ROWS;
-    constexpr int NLD = HEAD_ROWS * (HEAD_K / 4) / 256;
-    float4 v[NLD];
+    __shared__ __attribute__((aligned(16))) float head_lds[4][32 * HEAD_XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, n = lane & 31;
+    float *xs = head_lds[wave];
+    // B operands: W[n][8 j + 4 half + i], zero for the padding classes
+    float bw[HEAD_K / 8][4];
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int i = tid + 256 * j, r = i / (HEAD_K / 4), c4 = (i % (HEAD_K / 4)) * 4;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < n_rows) v[j] = *reinterpret_cast<const float4 *>(x + (r0 + r) * HEAD_K + c4);
+    for (int j = 0; j < HEAD_K / 8; ++j) {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < n_cls) w = *reinterpret_cast<const float4 *>(wd + n * HEAD_K + 8 * j + 4 * half);
+        bw[j][0] = w.x; bw[j][1] = w.y; bw[j][2] = w.z; bw[j][3] = w.w;
     }
-    for (int i = tid; i < n_cls * (HEAD_K / 4); i += 256)
-        reinterpret_cast<float4 *>(ws)[i] = reinterpret_cast<const float4 *>(wd)[i];
+    const float bias = n < n_cls ? bd[n] : 0.f;
+    const long n_tiles = (n_rows + 31) / 32;
+    const long gw = static_cast<long>(blockIdx.x) * 4 + wave, gstride = static_cast<long>(gridDim.x) * 4;
+    // piece c of this wave = quarter (c % 4) of its (c / 4)-th tile: 32 rows x 64 floats = 8 float4 per lane,
+    // float4 i = lane + 64 q: row i / 16, columns 4 (i % 16) .. + 3 (four whole 256-byte row pieces per load
+    // instruction), through a buffer descriptor that ends at the tile's last valid row (no bounds branch)
+    constexpr int NLD = 32 * (HEAD_KQ / 4) / 64;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 v[NLD];
+    const int ld_off = (lane >> 4) * (HEAD_K * 4) + (lane & 15) * 16;
+    auto load_piece = [&](long c) {
+        const long tile = gw + (c / HEAD_NQ) * gstride;
+        const long left = n_rows - tile * 32;
+        const int rows = tile < n_tiles ? static_cast<int>(left < 32 ? left : 32) : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x) + (rows ? tile * 32 * HEAD_K : 0), 0, rows * HEAD_K * 4, 0x00020000);
+        const int lo = ld_off + static_cast<int>(c % HEAD_NQ) * HEAD_KQ * 4;
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int i = tid + 256 * j, r = i / (HEAD_K / 4), c4 = (i % (HEAD_K / 4)) * 4;
-        *reinterpret_cast<float4 *>(xs + r * HEAD_XS + c4) = v[j];
-    }
-    __syncthreads();
-    const int r = tid & 63, cg = tid >> 6;
-    constexpr int NC = HEAD_MAX_SMALL / 4;
-    float acc[NC];
+        for (int q = 0; q < NLD; ++q)     // float4 lane + 64 q: row 4 q + lane / 16
+            v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo + q * 4 * HEAD_K * 4, 0, 0));
+    };
+    load_piece(0);
+    f32x16 acc;
+    // one piece: registers -> LDS, request the next piece, 8 steps of one LDS read + four MFMAs
+    auto piece = [&](long c, auto q_tag) {
+        constexpr int J0 = decltype(q_tag)::value * (HEAD_KQ / 8);
 #pragma unroll
-    for (int q = 0; q < NC; ++q) acc[q] = 0.f;
-    const float *xr = xs + r * HEAD_XS;
-    for (int k = 0; k < HEAD_K; k += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(xr + k);
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            const int c = cg + 4 * q;
-            if (c < n_cls) {                           // wave-uniform
-                const float4 w = *reinterpret_cast<const float4 *>(ws + c * HEAD_K + k);
-                acc[q] = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, acc[q]))));
-            }
+        for (int q = 0; q < NLD; ++q) {
+            const int i = lane + 64 * q;
+            *reinterpret_cast<f32x4 *>(xs + (i >> 4) * HEAD_XS + 4 * (i & 15)) = v[q];
         }
-    }
-    if (r0 + r < n_rows) {
+        wave_fence_lds();
+        load_piece(c + 1);
+        const float *xr = xs + n * HEAD_XS + 4 * half;
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            const int c = cg + 4 * q;
-            if (c < n_cls) probs[(r0 + r) * n_cls + c] = sigmoidf_fast(acc[q] + bd[c]);
+        for (int j = 0; j < HEAD_KQ / 8; ++j) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(xr + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[J0 + j][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[J0 + j][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[J0 + j][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[J0 + j][3], acc, 0, 0, 0);
+        }
+        wave_fence_lds();                              // the region is rewritten by the next piece
+    };
+#pragma unroll 1
+    for (long it = 0; gw + it * gstride < n_tiles; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        piece(HEAD_NQ * it, std::integral_constant<int, 0>{});
+        piece(HEAD_NQ * it + 1, std::integral_constant<int, 1>{});
+        piece(HEAD_NQ * it + 2, std::integral_constant<int, 2>{});
+        piece(HEAD_NQ * it + 3, std::integral_constant<int, 3>{});
+        const long row0 = (gw + it * gstride) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + acc_row(r, half);
+            if (n < n_cls && row < n_rows) probs[row * n_cls + n] = sigmoidf_fast(acc[r] + bias);
         }
     }
 }
@@ -1188,10 +1228,9 @@ int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, f
     sedmi::ProfileScope prof("head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
                              4.0 * n_rows * (HEAD_K + m->n_class));
     if (m->n_class <= HEAD_MAX_SMALL) {
-        const size_t lds = sizeof(float) * (HEAD_ROWS * HEAD_XS + m->n_class * HEAD_K);
-        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_small_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(head_small_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
+        // persistent waves over 32-row tiles: two workgroups of four waves per CU
+        const long wgs = std::min<long>(sedmi::ceil_div(n_rows, 128), 2L * m->num_cus);
+        hipLaunchKernelGGL(head_small_kernel, dim3(static_cast<unsigned>(wgs)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
                            m->n_class);
         SEDMI_CHECK_LAUNCH();
