@@ -12,29 +12,29 @@
 // the last block's output [clip][time][1][128] already is the [B, T', C]
 // sequence the GRU reads (no permute kernel).
 //
-// Arithmetic is float32 end to end on the f32-input matrix instruction
-// v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain), so the only differences
-// to the reference's CPU result come from summation order.
+// Arithmetic: by default ("split-f16") every float32 operand of a contraction is split into two f16
+// values and each product formed from three f16 MFMAs with float32 accumulation (conv_split.h), which
+// keeps float32-grade results at several times the f32 MFMA rate.  sedmi_crnn_set_precision selects the
+// exact-f32 twins instead (v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, so the only differences
+// to the reference's CPU result come from summation order).
 //
-// Kernels
-//   conv0_kernel      block 0 (1 input channel): VALU, one lane = one pooled
-//                     output position x 16 channels, weights as scalar operands.
-//   conv_mfma_kernel  blocks 1..6: implicit GEMM [positions] x [9*Cin] x [Cout].
-//                     A workgroup stages its input rows (+halo) once into LDS,
-//                     streams packed weights from L2 straight into registers
-//                     (no LDS round trip, no barrier in the main loop), then
-//                     runs the GLU's C x C linear as a second MFMA GEMM on the
-//                     BatchNorm output kept in LDS, multiplies by sigmoid(z)
-//                     from registers and average-pools pairs that sit in
-//                     adjacent accumulator registers of the same lane.
-//   linear_kernel     GRU input projections for all timesteps at once.
-//   gru_kernel        persistent recurrence: one workgroup = 32 clips x one
-//                     direction for all T' steps; W_hh (384x128) lives in
-//                     registers as MFMA B fragments for the whole kernel, h in
-//                     LDS (double buffered, one barrier per step), gates are
-//                     lane-local because each wave owns the r/z/n columns of
-//                     the same 32 hidden units.
-//   head_kernel       Linear(256 -> n_class) + sigmoid.
+// Kernels (split-f16 path / exact-f32 twin)
+//   conv0_split_kernel / conv0_kernel   block 0 (1 input channel), GLU linear folded into the conv
+//                     weights; on the matrix cores as a 32 x 9 matrix times 3x3 patches / on the VALU,
+//                     one lane = one pooled output position x 16 channels.
+//   conv_split_kernel (conv_split.h) / conv_mfma_kernel   blocks 1..6: implicit GEMM
+//                     [positions] x [9*Cin] x [Cout].  A workgroup stages its input rows (+halo) once
+//                     into LDS, streams packed weights from L2 straight into registers (no LDS round
+//                     trip, no barrier in the main loop), then runs the GLU's C x C linear as a second
+//                     MFMA GEMM on the BatchNorm output kept in LDS, multiplies by sigmoid(z) from
+//                     registers and average-pools pairs that sit in adjacent accumulator registers of
+//                     the same lane.
+//   linear_split_kernel (conv_split.h) / linear_kernel   GRU input projections for all timesteps at once.
+//   gru_split_kernel / gru_kernel   persistent recurrence: one workgroup = 32 clips x one direction for
+//                     all T' steps; W_hh lives in registers as MFMA B fragments for the whole kernel, h in
+//                     LDS (double buffered, one barrier per step), gates are lane-local because each wave
+//                     owns the r/z/n columns of the same hidden units.
+//   head_small_kernel (<= 32 classes, f32 MFMA) / head_kernel   Linear(256 -> n_class) + sigmoid.
 #include "common.h"
 
 #include <algorithm>
