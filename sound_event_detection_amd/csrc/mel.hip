@@ -218,37 +218,39 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     constexpr int FB = 32, ROUNDS = FB / WAVES;
     static_assert(ROUNDS % 4 == 0, "frames per wave and block must be a multiple of 4");
     float keep[2][4];              // [filter pass][frame of the group of four]; later passes write directly
-    const int blocks_per_clip = a.tiles_per_clip;
-    const long total_blocks = a.total_tiles;
-    // it-th frame of this wave: block blockIdx.x + (it / ROUNDS) * gridDim.x, frame (it % ROUNDS) * WAVES + wave in it
-    auto locate = [&](long it, long &clip, int &t) {
-        const long blk = blockIdx.x + (it / ROUNDS) * static_cast<long>(gridDim.x);
+    const unsigned blocks_per_clip = a.tiles_per_clip, total_blocks = static_cast<unsigned>(a.total_tiles);
+    // block -> (clip, first frame of this wave in it); one 32-bit division per block, not per frame
+    auto block_pos = [&](unsigned blk, unsigned &clip, int &tb) {
         clip = blk / blocks_per_clip;
         // a wave owns ROUNDS consecutive frames of the block, so that four of its results make one 16-byte store
-        t = static_cast<int>(blk - clip * blocks_per_clip) * FB + wave * ROUNDS + static_cast<int>(it % ROUNDS);
-        return blk < total_blocks;
+        tb = static_cast<int>(blk - clip * blocks_per_clip) * FB + wave * ROUNDS;
     };
-    // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use
-    auto load_raw = [&](long it, float (&r0)[NROW], float (&r1)[NROW]) {
-        long clip;
-        int t;
-        const bool live = locate(it, clip, t) && t < a.T;
-        const float *yc = a.y + (live ? clip : 0) * a.n_samples;
-        const long s_base = static_cast<long>(t) * a.hop - a.n_fft / 2;
+    // raw samples of one frame for this lane (two per active row); loaded one frame ahead of use, through a
+    // buffer descriptor that spans exactly the clip: samples before its start (negative offsets wrap to huge
+    // unsigned ones) and past its end read as zero -- the centred frames' padding -- with no branch, and a
+    // frame that does not exist gets an empty descriptor
+    auto load_raw = [&](bool live, unsigned clip, int t, float (&r0)[NROW], float (&r1)[NROW]) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.y) + static_cast<long>(live ? clip : 0) * a.n_samples, 0, live ? static_cast<int>(static_cast<unsigned>(a.n_samples) * 4u) : 0,
+            0x00020000);
+        // byte offset of this lane's first sample, modulo 2^32
+        const unsigned s0 = (static_cast<unsigned>(t) * a.hop - a.n_fft / 2 + 2 * (64 * ROW0 + lane)) * 4u;
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
-            const long s = s_base + 2 * (64 * (ROW0 + i) + lane);
-            r0[i] = (live && s >= 0 && s < a.n_samples) ? yc[s] : 0.f;
-            r1[i] = (live && s + 1 >= 0 && s + 1 < a.n_samples) ? yc[s + 1] : 0.f;
+            r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(s0 + i * 512), 0, 0));
+            r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(s0 + i * 512 + 4), 0, 0));
         }
     };
     float raw0[NROW], raw1[NROW];
-    load_raw(0, raw0, raw1);
+    // loop state: block blk of clip bclip, this wave's frames tb .. tb + ROUNDS - 1 of it, frame index fr
+    unsigned blk = blockIdx.x, bclip = 0;
+    int tb = 0, fr = 0;
+    if (blk < total_blocks) block_pos(blk, bclip, tb);
+    load_raw(blk < total_blocks && tb < a.T, bclip, tb, raw0, raw1);
 
-    for (long it = 0;; ++it) {
-        long clip;
-        int t;
-        if (!locate(it, clip, t)) break;
+    while (blk < total_blocks) {
+        const long clip = bclip;
+        const int t = tb + fr;
         // ---- stage 1: R1-point DFTs over n1, lane = n2 ---------------------
         float re[R1], im[R1];
 #pragma unroll
@@ -261,7 +263,14 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             re[ROW0 + i] = raw0[i] * w0[i];
             im[ROW0 + i] = raw1[i] * w1[i];
         }
-        load_raw(it + 1, raw0, raw1);                  // request this wave's next frame
+        // advance to this wave's next frame (the next one of the block, or the first one of its next block)
+        // and request its samples
+        if (++fr == ROUNDS) {
+            fr = 0;
+            blk += gridDim.x;
+            if (blk < total_blocks) block_pos(blk, bclip, tb);
+        }
+        load_raw(blk < total_blocks && tb + fr < a.T, bclip, tb + fr, raw0, raw1);
         if (t >= a.T) continue;                        // wave-uniform: past the end of the clip (last block)
         dif<R1>(re, im);
 #pragma unroll
@@ -611,6 +620,8 @@ template <int R1, int WAVES, int ROW0 = 0, int NROW = R1>
 static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
     a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, 32));     // work items: blocks of 32 frames
     a.total_tiles = n_clips * a.tiles_per_clip;
+    SEDMI_REQUIRE(a.total_tiles < (1LL << 31) - (1LL << 20), "too many frames in one call: %ld blocks of 32 frames",
+                  a.total_tiles);
     const size_t lds = mel_lds_bytes<R1, WAVES>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
     auto kern = mel_kernel<R1, WAVES, ROW0, NROW>;
@@ -639,7 +650,8 @@ int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, 
     if (n_clips == 0) return SEDMI_OK;
     SEDMI_REQUIRE(y && out, "null data pointer");
     const int64_t T = 1 + n_samples / p->hop;
-    SEDMI_REQUIRE(T < (1LL << 31) && n_samples < (1LL << 40), "clip too long");
+    // samples are addressed with 32-bit byte offsets inside a clip
+    SEDMI_REQUIRE(n_samples <= (1LL << 30) - (1LL << 14), "clip too long: at most 2^30 - 2^14 samples");
     MelArgs a{};
     a.y = y; a.n_samples = n_samples; a.T = static_cast<int>(T); a.hop = p->hop; a.n_fft = p->n_fft;
     a.win = p->d_win; a.tw_nc = p->d_tw_nc; a.tw_post = p->d_tw_post; a.zlo = p->zlo; a.zhi = p->zhi;
