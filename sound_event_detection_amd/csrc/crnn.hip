@@ -697,7 +697,8 @@ __global__ __launch_bounds__(256, 2) void head_small_kernel(const float *__restr
                                                             const float *__restrict__ bd, float *__restrict__ probs,
                                                             long n_rows, int n_cls) {
     __shared__ __attribute__((aligned(16))) float head_lds[4][32 * HEAD_XS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform by construction; keeps the tile's buffer descriptor scalar
     const int half = lane >> 5, n = lane & 31;
     float *xs = head_lds[wave];
     // B operands: W[n][8 j + 4 half + i], zero for the padding classes

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform by construction; tells the compiler so
     float2 *scr = scr_all + wave * G::SCR;
     float *melw = reinterpret_cast<float *>(smem + sizeof(float2) * G::SCR * WAVES);
     int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));
