@@ -237,8 +237,11 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
         const unsigned s0 = (static_cast<unsigned>(t) * a.hop - a.n_fft / 2 + 2 * (64 * ROW0 + lane)) * 4u;
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
-            r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(s0 + i * 512), 0, 0));
-            r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(s0 + i * 512 + 4), 0, 0));
+            // each offset is clamped on its own: with an odd hop a pair can be (sample -1, sample 0), whose offsets
+            // are 2^32 - 4 and 0 -- two loads the compiler must not fuse into one 8-byte access
+            const unsigned o0 = s0 + i * 512, o1 = o0 + 4;
+            r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(o0 < 0xfffffff0u ? o0 : 0xfffffff0u), 0, 0));
+            r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(o1 < 0xfffffff0u ? o1 : 0xfffffff0u), 0, 0));
         }
     };
     float raw0[NROW], raw1[NROW];

@@ -21,6 +21,8 @@ def _rel_err(got, ref):
     (16000, 1024, 64, 160, 400, 16000, 2),       # smaller transform
     (16000, 4096, 128, 640, 1280, 80000, 2),     # larger transform
     (16000, 2048, 40, 320, 640, 5000, 2),        # clip shorter than a few hops, ragged tile
+    (16000, 2048, 128, 321, 641, 15999, 2),      # odd hop, odd length: sample pairs straddle both clip edges
+    (22050, 1024, 64, 441, 1023, 22051, 3),
 ])
 def test_mel_matches_oracle(cfg):
     from sound_event_detection_amd import feature_extraction as fe
