@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + G::LDS_BYTES / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     // Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2, and vertically
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(128 * WN, (K <= 128 ? 2 : 1)) void linear_split_ker
     static_assert(N % NB == 0 && K % 64 == 0 && (128 * (K / 4)) % NTHR == 0, "unsupported linear geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
     const long n_tiles = (M + 127) / 128;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *_
                                                           float *__restrict__ y, int T, int Tp, int tiles_per_clip) {
     // x [clip][T][128], y [clip][Tp][64][16]
     __shared__ __attribute__((aligned(16))) float lds[(C0_ROWS + 4) * C0_RS];   // + 4 rows of zeros
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const long clip = blockIdx.x / tiles_per_clip;
     const int h20 = static_cast<int>(blockIdx.x % tiles_per_clip) * C0_TH;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(
     int H, int tiles_per_clip) {
     using G = ConvGeom<CIN, COUT, W>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     const long clip = blockIdx.x / tiles_per_clip;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ A
                                                      int N, int K) {
     constexpr int KC = 128, AS = KC + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     const long m0 = static_cast<long>(blockIdx.x) * 128;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void gru_kernel(
     float *__restrict__ out,           // [clip][T][2H]
     long n_clips, int T) {
     __shared__ __attribute__((aligned(16))) float hs[2][GRU_NB * GRU_HS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int dir = blockIdx.y;
     const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     float *__restrict__ out,           // [clip][T][2H]
     long n_clips, int T) {
     __shared__ __attribute__((aligned(16))) char hs[2][2][GRU_NB * GRU_PSB];     // [buffer][plane]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;        // column (A: row) within a 16-wide tile; k-group / row group
     const int dir = blockIdx.y;
     const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;

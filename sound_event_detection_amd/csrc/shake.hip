@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void shake_conv1_split_kernel(const float *
                                                                    float *__restrict__ u, int H, int W, int tiles_per_clip) {
     extern __shared__ __attribute__((aligned(16))) float c1_lds[];   // [C1_TR + 4][W + 2 * C1_HO]
     const int RS = W + 2 * C1_HO;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const long clip = blockIdx.x / tiles_per_clip;
     const int y0 = static_cast<int>(blockIdx.x % tiles_per_clip) * C1_TR;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     static_assert(MODE != MODE_GATE || CIN == CO, "the gate multiplies the conv input channel by channel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + G::PLANE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: hand each XCD a contiguous range of
     // tiles so that the tiles it runs back to back are neighbours and share their halos through L2
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float *__restr
     constexpr int KC = 128, PSB = KC * 2 + 16, PLANE = 128 * PSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + PLANE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     // Tile order.  Workgroup b runs on XCD b % 8, so XCD x takes the contiguous logical range
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
     constexpr int KW = GB_H / 4;                      // K slice per wave
     constexpr int PSB = KW * 2 + 16, PLANE = 32 * PSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int ug = blockIdx.x, dir = blockIdx.z;
     const long b0 = static_cast<long>(blockIdx.y) * 32;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                         int T, float scale) {
     __shared__ __attribute__((aligned(16))) float ks[AT_KB][AT_LD];
     __shared__ __attribute__((aligned(16))) float vs[AT_KB][AT_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int head = blockIdx.y;
     const long row0 = static_cast<long>(blockIdx.z) * T;
