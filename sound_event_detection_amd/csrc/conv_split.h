@@ -107,7 +107,7 @@ __device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int 
 // issued, m-tile 0 of the NEXT step (LDS offset next_off, < 0 for none) is requested into (ph, pl),
 // so that its LDS latency is covered by those MFMAs rather than paid at the head of the next step.
 //
-// hook(slot) runs after every MFMA (slot = running MFMA index, slot0 + 3 * (mt * NT + nt) + 0..2) and is
+// hook(slot) runs after every MFMA (slot = running MFMA index) and is
 // pinned there: vector-ALU work issued between the MFMAs of a wave overlaps with the MFMAs of the other
 // wave on the SIMD, while a long run of pure vector work next to a long run of MFMAs does not.
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits until every global store of
@@ -144,16 +144,15 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
             }
             if (MT > 1) __builtin_amdgcn_sched_barrier(0);
         }
+        // the three products of a tile are NT MFMAs apart: consecutive MFMAs never wait for each other's result
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int slot = slot0 + 3 * (mt * NT + nt);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(val[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
-            if (HOOKED) { hook(slot); __builtin_amdgcn_sched_barrier(0); }
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.l[nt], acc[mt][nt], 0, 0, 0);
-            if (HOOKED) { hook(slot + 1); __builtin_amdgcn_sched_barrier(0); }
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vah[mt], b.h[nt], acc[mt][nt], 0, 0, 0);
-            if (HOOKED) { hook(slot + 2); __builtin_amdgcn_sched_barrier(0); }
-        }
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 0 ? val[mt] : vah[mt], w == 1 ? b.l[nt] : b.h[nt],
+                                                                     acc[mt][nt], 0, 0, 0);
+                if (HOOKED) { hook(slot0 + (3 * mt + w) * NT + nt); __builtin_amdgcn_sched_barrier(0); }
+            }
     }
 }
 
