@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__
 // The 32 rows are ordered so that a lane's 16 accumulator registers hold z (registers 0-7) and lin
 // (8-15) of the SAME eight channels 8*half .. 8*half+7: no cross-lane traffic for the gate.
 // z rows carry -log2(e) * z * 2^Sz (so sigmoid = 1 / (1 + exp2(acc * 2^-Sz))), lin rows 0.25 * lin * 2^Sl;
-// the biases enter as the initial accumulator.  Lanes 32-63 supply contraction indices 8-15, of which
-// only tap 8 is real: they read it through their own base address and read zeros for the rest.
+// the biases enter as the initial accumulator.  The contraction runs over two patch rows x four patch
+// columns per lane half (12 real taps' worth of slots for 9 taps: the column the member does not cover meets a
+// zero weight), which lets the four members share their split patch rows.
 #ifndef C0_TH_V
 #define C0_TH_V 8
 #endif
@@ -183,7 +184,7 @@ constexpr int C0_HO = 4;                    // LDS column of input column 0 (kee
 constexpr int C0_RS = 128 + 2 * C0_HO;      // LDS row stride in floats
 constexpr int C0_ROWS = 2 * C0_TH + 2;      // staged input rows
 __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *__restrict__ x,
-                                                          const uint4 *__restrict__ wpk,     // [2 planes][32 rows][16] f16
+                                                          const uint4 *__restrict__ wpk,     // [2 dx][2 planes][32 rows][16] f16
                                                           const float *__restrict__ bias32,  // [32] scaled row biases
                                                           float zscale, float lscale,        // 2^-Sz, 2^-Sl
                                                           float *__restrict__ y, int T, int Tp, int tiles_per_clip) {
@@ -203,8 +204,13 @@ __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *_
     for (int i = tid; i < C0_ROWS * 2; i += 256) lds[(i >> 1) * C0_RS + ((i & 1) ? C0_HO + 128 : C0_HO - 1)] = 0.f;
     for (int i = tid; i < 4 * C0_RS; i += 256) lds[C0_ROWS * C0_RS + i] = 0.f;
 
-    const uint4 wh = wpk[col32 * 2 + half], wl = wpk[64 + col32 * 2 + half];
-    const f16x8 a_hi = __builtin_bit_cast(f16x8, wh), a_lo = __builtin_bit_cast(f16x8, wl);
+    // A operands for the two horizontal members of the pooling window (dx = 0, 1): [dx][plane][32 rows][16]
+    f16x8 a_hi[2], a_lo[2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+        a_hi[dx] = __builtin_bit_cast(f16x8, wpk[(dx * 2 + 0) * 64 + col32 * 2 + half]);
+        a_lo[dx] = __builtin_bit_cast(f16x8, wpk[(dx * 2 + 1) * 64 + col32 * 2 + half]);
+    }
     f32x16 cinit;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = bias32[acc_row(r, half)];
@@ -216,24 +222,37 @@ __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *_
         const int prow = gi >> 1, w2 = 32 * (gi & 1) + col32, h2 = h20 + prow;
         // patch[r][c] of this pooled position = lds[(2 * prow + r) * RS + HO - 1 + 2 * w2 + c]
         const int pb = (2 * prow) * C0_RS + C0_HO - 1 + 2 * w2;
-        const float *p0 = lds + (half ? pb + 2 * C0_RS + 2 : pb);        // index 0: tap 0 / tap 8
-        const float *pz = lds + (half ? C0_ROWS * C0_RS : pb);          // indices 1..7: taps 1..7 / zeros
+        // A lane contributes eight contraction indices = two patch rows x four patch columns: lanes 0-31 rows
+        // dy, dy + 1 of vertical member dy, lanes 32-63 row dy + 2 and four zeros.  Every patch row is split
+        // into f16 halves once and serves both vertical members and -- the column shift being in the A
+        // operand -- both horizontal ones.  Row slots P, Q, R = patch rows 0, 1, 2 (lanes 0-31) / rows 2, 3 and
+        // a zeroed LDS row (lanes 32-63): member dy = 1 contracts (Q, R) in every lane, dy = 0 (P, Q) or (P, R).
+        const float *rp[3] = {lds + pb + (half ? 2 * C0_RS : 0), lds + pb + (half ? 3 * C0_RS : C0_RS),
+                              lds + (half ? C0_ROWS * C0_RS : pb + 2 * C0_RS)};
+        unsigned sh[3][2], sl[3][2];                     // [slot][column pair]: packed f16 hi / lo halves
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            split2_f16(rp[k][0], rp[k][1], sh[k][0], sl[k][0]);
+            split2_f16(rp[k][2], rp[k][3], sh[k][1], sl[k][1]);
+        }
         f32x16 acc[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int dy = p >> 1, dx = p & 1;
-            float v[8];
-            v[0] = p0[dy * C0_RS + dx];
+        for (int dy = 0; dy < 2; ++dy) {
+            unsigned yh[2], yl[2];                       // second row of the member
 #pragma unroll
-            for (int j = 1; j < 8; ++j) v[j] = pz[(dy + j / 3) * C0_RS + dx + j % 3];
-            unsigned bh[4], bl[4];
+            for (int c = 0; c < 2; ++c) {
+                yh[c] = dy ? sh[2][c] : (half ? sh[2][c] : sh[1][c]);
+                yl[c] = dy ? sl[2][c] : (half ? sl[2][c] : sl[1][c]);
+            }
+            const f16x8 b_hi = __builtin_bit_cast(f16x8, make_uint4(sh[dy][0], sh[dy][1], yh[0], yh[1]));
+            const f16x8 b_lo = __builtin_bit_cast(f16x8, make_uint4(sl[dy][0], sl[dy][1], yl[0], yl[1]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split2_f16(v[2 * j], v[2 * j + 1], bh[j], bl[j]);
-            const f16x8 b_hi = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-            const f16x8 b_lo = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, cinit, 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[p], 0, 0, 0);
+            for (int dx = 0; dx < 2; ++dx) {
+                const int p = 2 * dy + dx;
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[dx], b_hi, cinit, 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[dx], b_lo, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[dx], b_hi, acc[p], 0, 0, 0);
+            }
         }
         float o[8];
 #pragma unroll
@@ -780,7 +799,7 @@ constexpr int kCnnChunk = SEDMI_CNN_CHUNK;     // clips per pass through the con
 struct sedmi_crnn {
     int n_class = 0, device = 0, num_cus = 0;
     Conv0Params *d_c0 = nullptr;
-    uint16_t *d_c0s = nullptr;         // block 0 for the matrix cores: split-f16 folded weights [2][32][16]
+    uint16_t *d_c0s = nullptr;         // block 0 for the matrix cores: split-f16 folded weights [2 dx][2][32][16]
     float *d_c0bias = nullptr;         // and the scaled row biases
     float c0_zscale = 1.f, c0_lscale = 1.f;
     float *d_wp[SEDMI_CRNN_LAYERS] = {};   // packed conv weights (blocks 1..6)
@@ -1059,8 +1078,13 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
         for (int i = 0; i < 32; ++i)
             for (int k = 0; k < 9; ++k) (is_z(i) ? zw[nz++] : lw[nl++]) = rows[i][k];
         const int Sz = split_scale_exp(zw, nz), Sl = split_scale_exp(lw, nl);
-        auto c0s = pack_split(1, 32, 0, [&](int, int k16, int n) {
-            return k16 < 9 ? std::ldexp(rows[n][k16], is_z(n) ? Sz : Sl) : 0.f;
+        // contraction index k16 = 8 * lane half + 4 * e + c: patch row ky = e (lanes 0-31) or 2 (lanes 32-63, e = 0
+        // only), patch column c; horizontal member dx sees kernel column kx = c - dx
+        auto c0s = pack_split(2, 32, 0, [&](int dx, int k16, int n) {
+            const int hf = k16 >> 3, e = (k16 >> 2) & 1, c = k16 & 3, kx = c - dx;
+            if ((hf && e) || kx < 0 || kx > 2) return 0.f;
+            const int ky = hf ? 2 : e;
+            return std::ldexp(rows[n][ky * 3 + kx], is_z(n) ? Sz : Sl);
         });
         std::vector<float> c0bias(32);
         for (int i = 0; i < 32; ++i) c0bias[i] = std::ldexp(rbias[i], is_z(i) ? Sz : Sl);
