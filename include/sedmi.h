@@ -76,7 +76,9 @@ int sedmi_mel_filterbank(const sedmi_mel_plan *plan, float *host_out);
  * mel-major array librosa returns.  The reference then re-reads the same
  * bytes as [T, n_mels] (np.reshape at feature_extraction.py:49-50), which
  * needs no data movement: pass `out` on as the [n_clips, T, n_mels] feature.
- * mean / istd: device float32 [n_mels], read only with SEDMI_MEL_NORMALISE. */
+ * mean / istd: device float32 [n_mels], read only with SEDMI_MEL_NORMALISE.
+ * Limits (SEDMI_EINVAL beyond them): n_samples <= 2^30 - 2^14 per clip (samples are
+ * addressed with 32-bit byte offsets inside a clip), n_clips * ceil(T / 32) < 2^31 - 2^20. */
 int sedmi_melspec_f32(const sedmi_mel_plan *plan, const float *y, int64_t n_clips,
                       int64_t n_samples, int flags, const float *mean, const float *istd,
                       float *out, void *stream);
