@@ -559,13 +559,25 @@ __global__ __launch_bounds__(256) void to_reference_order_kernel(const float *__
 // scores sit in one lane pair: the softmax needs one cross-lane exchange, and the probabilities are
 // already laid out as the B operand of  O^T += V^T . P^T.
 // ---------------------------------------------------------------------------
-constexpr int AT_D = 128, AT_KB = 32, AT_LD = AT_D + 4;
+constexpr int AT_D = 128, AT_KB = 32;
 
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv,   // [clip*T + t][3*1024]
-                                                        float *__restrict__ out,         // [clip*T + t][1024]
-                                                        int T, float scale) {
-    __shared__ __attribute__((aligned(16))) float ks[AT_KB][AT_LD];
-    __shared__ __attribute__((aligned(16))) float vs[AT_KB][AT_LD];
+// Multi-head attention (8 heads x 128, no mask) as a streaming softmax over blocks of 32 keys, on the f16 matrix
+// cores with the split-f16 arithmetic of conv_split.h (both operands of both products are activations: all four
+// are split on the fly).  Per block of 32 keys a workgroup stages K as hi/lo
+// f16 planes [key][dim] and V TRANSPOSED, [dim][key slot], so that both products read their LDS operand with one
+// 16-byte load per fragment:  S^T = K . Q^T (A = K from LDS, B = this lane's query from registers), then
+// O^T += V^T . P^T (A = V^T from LDS, B = the probabilities straight out of the accumulator registers of S^T --
+// the key slots of V^T are numbered in the order in which a lane holds its keys there).  A query's scores,
+// maximum, sum and output column all sit in one lane pair (one shfl_xor 32 per reduction); 48 MFMAs of 32 cycles
+// per key block and wave (the exact-f32 form on v_mfma_f32_32x32x2_f32 took 128 of 64).
+constexpr int AT_KSB = AT_D * 2 + 16;      // bytes per key row of a K plane
+constexpr int AT_VSB = AT_KB * 2 + 16;     // bytes per dim row of a V^T plane
+
+__global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__restrict__ qkv,   // [clip*T + t][3*1024]
+                                                              float *__restrict__ out,         // [clip*T + t][1024]
+                                                              int T, float scale) {
+    __shared__ __attribute__((aligned(16))) char kh[AT_KB * AT_KSB], kl[AT_KB * AT_KSB];
+    __shared__ __attribute__((aligned(16))) char vth[AT_D * AT_VSB], vtl[AT_D * AT_VSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int head = blockIdx.y;
@@ -573,12 +585,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     const int q = blockIdx.x * 128 + wave * 32 + col32;
     const float *base = qkv + row0 * 3072 + head * AT_D;
 
-    float qr[64];                       // this lane's query, k = 8g + 4*half + i  ->  qr[4g + i]
+    // B operand of S^T: this lane's (scaled) query, dims 16 ks + 8 half + 0..7 of k-step ks
+    f16x8 qh[AT_D / 16], ql[AT_D / 16];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < T) v = *reinterpret_cast<const float4 *>(base + static_cast<long>(q) * 3072 + 8 * g + 4 * half);
-        qr[4 * g] = v.x * scale; qr[4 * g + 1] = v.y * scale; qr[4 * g + 2] = v.z * scale; qr[4 * g + 3] = v.w * scale;
+    for (int ks = 0; ks < AT_D / 16; ++ks) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (q < T) {
+            const float *p = base + static_cast<long>(q) * 3072 + 16 * ks + 8 * half;
+            v0 = *reinterpret_cast<const float4 *>(p);
+            v1 = *reinterpret_cast<const float4 *>(p + 4);
+        }
+        uint4 h, l;
+        split2_f16(v0.x * scale, v0.y * scale, h.x, l.x);
+        split2_f16(v0.z * scale, v0.w * scale, h.y, l.y);
+        split2_f16(v1.x * scale, v1.y * scale, h.z, l.z);
+        split2_f16(v1.z * scale, v1.w * scale, h.w, l.w);
+        qh[ks] = __builtin_bit_cast(f16x8, h);
+        ql[ks] = __builtin_bit_cast(f16x8, l);
     }
     f32x16 o[4];
 #pragma unroll
@@ -598,26 +621,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                 kv = *reinterpret_cast<const float4 *>(p + 1024);
                 vv = *reinterpret_cast<const float4 *>(p + 2048);
             }
-            *reinterpret_cast<float4 *>(&ks[key][c4]) = kv;
-            *reinterpret_cast<float4 *>(&vs[key][c4]) = vv;
+            uint2 hi, lo;
+            split2_f16(kv.x, kv.y, hi.x, lo.x);
+            split2_f16(kv.z, kv.w, hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(kh + key * AT_KSB + c4 * 2) = hi;
+            *reinterpret_cast<uint2 *>(kl + key * AT_KSB + c4 * 2) = lo;
+            // key = acc_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h sits in slot 16 (r >> 3) + 8 h + (r & 7) of V^T's rows
+            const int h = (key >> 2) & 1, r = (key & 3) + 4 * (key >> 3);
+            const int slot = 16 * (r >> 3) + 8 * h + (r & 7);
+            split2_f16(vv.x, vv.y, hi.x, lo.x);
+            split2_f16(vv.z, vv.w, hi.y, lo.y);
+            char *ph = vth + c4 * AT_VSB + slot * 2, *pl = vtl + c4 * AT_VSB + slot * 2;
+            *reinterpret_cast<unsigned short *>(ph) = static_cast<unsigned short>(hi.x);
+            *reinterpret_cast<unsigned short *>(ph + AT_VSB) = static_cast<unsigned short>(hi.x >> 16);
+            *reinterpret_cast<unsigned short *>(ph + 2 * AT_VSB) = static_cast<unsigned short>(hi.y);
+            *reinterpret_cast<unsigned short *>(ph + 3 * AT_VSB) = static_cast<unsigned short>(hi.y >> 16);
+            *reinterpret_cast<unsigned short *>(pl) = static_cast<unsigned short>(lo.x);
+            *reinterpret_cast<unsigned short *>(pl + AT_VSB) = static_cast<unsigned short>(lo.x >> 16);
+            *reinterpret_cast<unsigned short *>(pl + 2 * AT_VSB) = static_cast<unsigned short>(lo.y);
+            *reinterpret_cast<unsigned short *>(pl + 3 * AT_VSB) = static_cast<unsigned short>(lo.y >> 16);
         }
         __syncthreads();
-        f32x16 s;
+        // S^T[key][query]: A row = key col32, B column = query col32
+        f32x16 sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float4 a = *reinterpret_cast<const float4 *>(&ks[col32][8 * g + 4 * half]);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qr[4 * g], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qr[4 * g + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qr[4 * g + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qr[4 * g + 3], s, 0, 0, 0);
+        for (int ks = 0; ks < AT_D / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(kh + col32 * AT_KSB + ks * 32 + 16 * half);
+            const f16x8 al = *reinterpret_cast<const f16x8 *>(kl + col32 * AT_KSB + ks * 32 + 16 * half);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], sc, 0, 0, 0);
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (kb0 + acc_row(r, half) >= T) s[r] = -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            if (kb0 + acc_row(r, half) >= T) sc[r] = -INFINITY;
+            mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);            // finite: key kb0 < T is in every block
@@ -625,8 +666,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
-            psum += s[r];
+            sc[r] = __expf(sc[r] - m_new);
+            psum += sc[r];
         }
         psum += __shfl_xor(psum, 32);
         l = fmaf(l, corr, psum);
@@ -635,12 +676,28 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+        // B operand of O^T: this lane's probabilities, registers 8 ks .. 8 ks + 7 = key slots 16 ks + 8 half + 0..7
+        f16x8 pph[2], ppl[2];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float *vrow = &vs[acc_row(j, half)][col32];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * nt], s[j], o[nt], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 h, lw;
+            split2_f16(sc[8 * ks], sc[8 * ks + 1], h.x, lw.x);
+            split2_f16(sc[8 * ks + 2], sc[8 * ks + 3], h.y, lw.y);
+            split2_f16(sc[8 * ks + 4], sc[8 * ks + 5], h.z, lw.z);
+            split2_f16(sc[8 * ks + 6], sc[8 * ks + 7], h.w, lw.w);
+            pph[ks] = __builtin_bit_cast(f16x8, h);
+            ppl[ks] = __builtin_bit_cast(f16x8, lw);
         }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(vth + (32 * nt + col32) * AT_VSB + (16 * ks + 8 * half) * 2);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(vtl + (32 * nt + col32) * AT_VSB + (16 * ks + 8 * half) * 2);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, pph[ks], o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ppl[ks], o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pph[ks], o[nt], 0, 0, 0);
+            }
     }
     if (q < T) {
         const float inv = 1.0f / l;
@@ -1025,7 +1082,7 @@ int run_encoder(const sedmi_shake_transformer *m, long n, int T4, const ShakeScr
         {
             sedmi::ProfileScope prof("shake_tf_attention", s, 4.0 * n * 8 * static_cast<double>(T4) * T4 * AT_D,
                                      4.0 * rows * 4096.0);
-            hipLaunchKernelGGL(attention_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128)), 8, static_cast<unsigned>(n)),
+            hipLaunchKernelGGL(attention_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128)), 8, static_cast<unsigned>(n)),
                                dim3(256), 0, s, sc.qkv, sc.att, T4, 1.0f / std::sqrt(static_cast<float>(AT_D)));
             SEDMI_CHECK_LAUNCH();
         }
