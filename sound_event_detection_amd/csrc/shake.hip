@@ -553,11 +553,7 @@ __global__ __launch_bounds__(256) void to_reference_order_kernel(const float *__
 // ---------------------------------------------------------------------------
 // multi-head self-attention, head_dim 128, no mask (TransformerEncoderLayer, batch_first):
 // one workgroup = one (clip, head) x 128 queries, a wave = 32 queries; keys/values stream through
-// LDS 32 at a time with the running-max softmax.  Exact-f32 MFMAs (v_mfma_f32_32x32x2_f32): both
-// operands are activations, and attention is a few percent of the layer's work.
-// The score tile is computed transposed (rows = keys, columns = queries) so that a query's 32
-// scores sit in one lane pair: the softmax needs one cross-lane exchange, and the probabilities are
-// already laid out as the B operand of  O^T += V^T . P^T.
+// LDS 32 at a time with the running-max softmax.
 // ---------------------------------------------------------------------------
 constexpr int AT_D = 128, AT_KB = 32;
 
