@@ -308,7 +308,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                     tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
                     const int yy = ty0 + ty, xx = tx0 + tx;
                     float uc = 0.f;
-                    if (lane_ok && yy < H && xx < W) uc = xc[(static_cast<long>(yy) * W + xx) * CIN + ch];
+                    if constexpr (G::NCHUNK == 1) {
+                        // the centre input is still in the staged planes (hi + lo restores it to 2^-22; positions
+                        // outside the image were staged as zero)
+                        const int poff = ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
+                        if (lane_ok)
+                            uc = static_cast<float>(*reinterpret_cast<const _Float16 *>(plane_h + poff)) +
+                                 static_cast<float>(*reinterpret_cast<const _Float16 *>(plane_l + poff));
+                    } else {
+                        if (lane_ok && yy < H && xx < W) uc = xc[(static_cast<long>(yy) * W + xx) * CIN + ch];
+                    }
                     const float val = fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
                     sum += val;
                     if ((r % WIN) == WIN - 1) {
