@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         SPLIT_TICK(3);
     }
 
-    // ---- BatchNorm affine; z stays in the accumulators and goes to LDS as hi/lo planes
+    // ---- BatchNorm affine (bn_s, bn_t arrive multiplied by -log2 e: the accumulators hold z' = -log2(e) z, the
+    // exponent of the sigmoid; g_s undoes the factor for the GLU product); z' stays in the accumulators and goes
+    // to LDS as hi/lo planes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float sc = bn_s[ncol + 32 * nt], sh = bn_t[ncol + 32 * nt];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     // sigmoid in two halves (each ends in a transcendental, whose latency the other half's covers)
     auto sig_a = [&](int p, int v) {
         f32x16 &a = acc[p * MG + v / (16 * NT)][(v / 16) % NT];
-        a[v % 16] = __builtin_amdgcn_exp2f(a[v % 16] * -1.4426950408889634f);
+        a[v % 16] = __builtin_amdgcn_exp2f(a[v % 16]);
     };
     auto sig_b = [&](int p, int v) {
         f32x16 &a = acc[p * MG + v / (16 * NT)][(v / 16) % NT];

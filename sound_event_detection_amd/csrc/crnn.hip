@@ -807,7 +807,7 @@ struct sedmi_crnn {
     float *d_gp[SEDMI_CRNN_LAYERS] = {}, *d_gb[SEDMI_CRNN_LAYERS] = {};
     // split-f16 variants (blocks 1..6): packed hi/lo weights, scales with the power-of-two weight scale undone
     uint16_t *d_wps[SEDMI_CRNN_LAYERS] = {}, *d_gps[SEDMI_CRNN_LAYERS] = {};
-    float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {}, *d_gbh[SEDMI_CRNN_LAYERS] = {};
+    float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_ts[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {}, *d_gbh[SEDMI_CRNN_LAYERS] = {};
     uint16_t *d_wihs[2] = {};          // split-f16 GRU input-projection weights
     float wih_oscale[2] = {1.f, 1.f};
     uint16_t *d_whhs[2] = {};          // split-f16 GRU recurrent weights, both directions
@@ -856,7 +856,7 @@ int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, 
                              pos * 4.0 * (CIN + COUT / 2.0));
     const unsigned n_tiles = static_cast<unsigned>(n_clips * tiles);
     hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), lds, s, x,
-                       reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_t[layer],
+                       reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_ts[layer],
                        reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles,
                        n_tiles);
     SEDMI_CHECK_LAUNCH();
@@ -1120,14 +1120,19 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
             auto gps = pack_split(co / 16, co, Sg, [&](int kidx, int k16, int n) {
                 return gsrc[static_cast<size_t>(n) * co + kidx * 16 + k16];
             });
-            // the average pool's factor 1/2 rides along in the GLU scale and bias of the split path
-            std::vector<float> ss(co), gs(co, std::ldexp(1.0f, -Sg - 1)), gbh(co);
+            // The split path keeps z' = -log2(e) * z (so that the sigmoid's exponential is a bare exp2 of it):
+            // the factor goes into the BatchNorm affine here and comes back out through the GLU scale, which
+            // also carries the average pool's factor 1/2 (as does the GLU bias).
+            const float kNegLog2e = -1.4426950408889634f, kNegLn2 = -0.6931471805599453f;
+            std::vector<float> ss(co), ts(co), gs(co, std::ldexp(kNegLn2, -Sg - 1)), gbh(co);
             for (int c = 0; c < co; ++c) {
-                ss[c] = std::ldexp(s[i][c], -S);
+                ss[c] = std::ldexp(s[i][c], -S) * kNegLog2e;
+                ts[c] = t[i][c] * kNegLog2e;
                 gbh[c] = 0.5f * w->glu_b[i][c];
             }
             if ((rc = sedmi::upload(&m->d_wps[i], wps)) || (rc = sedmi::upload(&m->d_gps[i], gps)) ||
-                (rc = sedmi::upload(&m->d_ss[i], ss)) || (rc = sedmi::upload(&m->d_gs[i], gs)) ||
+                (rc = sedmi::upload(&m->d_ss[i], ss)) || (rc = sedmi::upload(&m->d_ts[i], ts)) ||
+                (rc = sedmi::upload(&m->d_gs[i], gs)) ||
                 (rc = sedmi::upload(&m->d_gbh[i], gbh)))
                 return fail(rc);
         }
@@ -1193,7 +1198,7 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
     for (int i = 0; i < SEDMI_CRNN_LAYERS; ++i) {
         (void)hipFree(m->d_wp[i]); (void)hipFree(m->d_s[i]); (void)hipFree(m->d_t[i]);
         (void)hipFree(m->d_gp[i]); (void)hipFree(m->d_gb[i]);
-        (void)hipFree(m->d_wps[i]); (void)hipFree(m->d_gps[i]); (void)hipFree(m->d_ss[i]); (void)hipFree(m->d_gs[i]);
+        (void)hipFree(m->d_wps[i]); (void)hipFree(m->d_gps[i]); (void)hipFree(m->d_ss[i]); (void)hipFree(m->d_ts[i]); (void)hipFree(m->d_gs[i]);
         (void)hipFree(m->d_gbh[i]);
     }
     for (int l = 0; l < 2; ++l) {
