@@ -195,3 +195,16 @@ def test_rcnn_long_recording_vs_oracle(model):
     got = model(x.cuda(), al).cpu().numpy()
     assert got.shape == want.shape == (1, 600, 10)
     np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
+def test_gemm_rows_cross_a_tile_boundary_vs_oracle(model, tmodel):
+    # 3 clips x 100 tokens = 300 GEMM rows: one full 256-row tile and a second one with 44 valid rows
+    from oracle import shake
+    x = torch.from_numpy(synth.synth_shake_feats(13, 3, 400))
+    al = [0.35, 0.55, 0.15]
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    np.testing.assert_allclose(model(x.cuda(), al).cpu().numpy(), shake.shake_rcnn_forward(sd, x, al).numpy(),
+                               rtol=0, atol=ATOL_LOGITS)
+    sd = synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0)
+    np.testing.assert_allclose(tmodel(x.cuda(), al).cpu().numpy(), shake.shake_transformer_forward(sd, x, al).numpy(),
+                               rtol=0, atol=ATOL_LOGITS)
