@@ -480,6 +480,25 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
     char *plane_h = smem + wave * 2 * PLANE, *plane_l = plane_h + PLANE;
     const float *hp = h_prev + (static_cast<long>(dir) * n_clips) * GB_H;
 
+    // The gate inputs of this thread's four (clip, unit) elements are requested first: gi streams from HBM, and
+    // asked for only after the GEMM its latency would sit at the end of every step.
+    float pg[4][3], ph_prev[4], pb;
+    {
+        const int jj = tid & 31, j = ug * 32 + jj;
+        pb = bhn[dir * GB_H + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long b = b0 + (tid >> 5) + 8 * q;
+            const bool ok = b < n_clips;
+            const float *gp = gi + (((ok ? b : 0) * T + t) * 2 + dir) * (3L * GB_H) + j;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pg[q][g] = ok ? gp[g * GB_H] : 0.f;
+            ph_prev[q] = ok ? hp[b * GB_H + j] : 0.f;
+        }
+    }
+
+    const uint4 *bp = whh + (static_cast<long>(dir) * (GB_H / 16) + wave * (KW / 16)) * (3 * GB_H * 4) +
+                      (ug * 96 + col32) * 2 + half;
     // each wave stages its own K slice of h for the 32 clips
     constexpr int NLD = 32 * (KW / 4) / 64;
     float4 v[NLD];
@@ -506,8 +525,6 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][g][r] = 0.f;
     const char *ah[1] = {plane_h + col32 * PSB + 16 * half}, *al[1] = {plane_l + col32 * PSB + 16 * half};
-    const uint4 *bp = whh + (static_cast<long>(dir) * (GB_H / 16) + wave * (KW / 16)) * (3 * GB_H * 4) +
-                      (ug * 96 + col32) * 2 + half;
     split_gemm<1, 3, KW / 16>(acc, ah, al, bp, 3 * GB_H, [](int i) { return i * 32; });
 
     // reduce the four K slices through LDS, then the gate math: thread -> (clip row, unit)
@@ -518,12 +535,11 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wave * 3 + g) * 32 + acc_row(r, half)) * 32 + col32] = acc[0][g][r];
     __syncthreads();
-    const float *hprow = hp;
     float *hn = h_next + (static_cast<long>(dir) * n_clips) * GB_H;
-    for (int e = tid; e < 32 * 32; e += 256) {
-        const int row = e >> 5, jj = e & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (tid >> 5) + 8 * q, jj = tid & 31;
         const long b = b0 + row;
-        if (b >= n_clips) continue;
         const int j = ug * 32 + jj;
         float gh[3];
 #pragma unroll
@@ -533,14 +549,14 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
             for (int w = 0; w < 4; ++w) s += red[((w * 3 + g) * 32 + row) * 32 + jj];
             gh[g] = s * whh_oscale;
         }
-        const float *gp = gi + ((b * T + t) * 2 + dir) * (3L * GB_H) + j;
-        const float rg = sigmoidf_fast(gp[0] + gh[0]);
-        const float zg = sigmoidf_fast(gp[GB_H] + gh[1]);
-        const float ng = tanhf_fast(fmaf(rg, gh[2] + bhn[dir * GB_H + j], gp[2 * GB_H]));
-        const float hprev = hprow[b * GB_H + j];
-        const float hv = fmaf(zg, hprev - ng, ng);
-        hn[b * GB_H + j] = hv;
-        out[(b * T + t) * (2L * GB_H) + dir * GB_H + j] = hv;
+        const float rg = sigmoidf_fast(pg[q][0] + gh[0]);
+        const float zg = sigmoidf_fast(pg[q][1] + gh[1]);
+        const float ng = tanhf_fast(fmaf(rg, gh[2] + pb, pg[q][2]));
+        const float hv = fmaf(zg, ph_prev[q] - ng, ng);
+        if (b < n_clips) {
+            hn[b * GB_H + j] = hv;
+            out[(b * T + t) * (2L * GB_H) + dir * GB_H + j] = hv;
+        }
     }
 }
 
