@@ -91,11 +91,12 @@ struct SplitB {
 
 // b: packed weights of one k-step, [plane][N][16] f16 as uint4 (16 B) units, already offset to
 // this lane's (column, half) of n-tile 0; n2 = 2 * N (uint4 units between the hi and lo planes).
-template <int NT>
+// CTS: distance between a wave's column tiles, in tiles (1 = neighbouring tiles).
+template <int NT, int CTS = 1>
 __device__ __forceinline__ void split_load_b(SplitB<NT> &f, const uint4 *b, int n2) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const uint4 h = b[nt * 64], l = b[n2 + nt * 64];
+        const uint4 h = b[nt * 64 * CTS], l = b[n2 + nt * 64 * CTS];
         f.h[nt] = __builtin_bit_cast(f16x8, h);
         f.l[nt] = __builtin_bit_cast(f16x8, l);
     }
@@ -160,7 +161,7 @@ __device__ __forceinline__ void split_step(f32x16 (&acc)[MT][NT], const char *(&
 // before the MFMAs of step i issue (their latency is several hundred cycles).
 // a_off(i) = LDS byte offset of step i relative to ah/al; N = columns of the packed weight matrix
 // (B advances by 4*N uint4 per k-step: 2 planes x N columns x 32 B).
-template <int MT, int NT, int NSTEPS, int D = SPLIT_BDIST, typename AOff, typename Hook = SplitNoHook>
+template <int MT, int NT, int NSTEPS, int D = SPLIT_BDIST, int CTS = 1, typename AOff, typename Hook = SplitNoHook>
 __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
                                            const uint4 *b, int N, AOff a_off, Hook hook = Hook()) {
     const int BS = N * 4, n2 = N * 2;
@@ -169,14 +170,14 @@ __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&
     SplitB<NT> bb[NB];
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < NSTEPS) split_load_b<NT>(bb[d], b + d * BS, n2);
+        if (d < NSTEPS) split_load_b<NT, CTS>(bb[d], b + d * BS, n2);
     f16x8 ph = *reinterpret_cast<const f16x8 *>(ah[0] + a_off(0));
     f16x8 pl = *reinterpret_cast<const f16x8 *>(al[0] + a_off(0));
 #pragma unroll
     for (int i = 0; i < NSTEPS; ++i) {
         // sched_barrier pins "request the later step's weights, then run this step": left alone, the
         // scheduler sinks every load to just above its first use and the wave stalls on each one
-        if (i + D < NSTEPS) split_load_b<NT>(bb[(i + D) % NB], b + (i + D) * BS, n2);
+        if (i + D < NSTEPS) split_load_b<NT, CTS>(bb[(i + D) % NB], b + (i + D) * BS, n2);
         __builtin_amdgcn_sched_barrier(0);
         split_step<MT, NT, Hook>(acc, ah, al, a_off(i), i + 1 < NSTEPS ? a_off(i + 1) : -1, bb[i % NB], ph, pl,
                                  i * 3 * MT * NT, hook);

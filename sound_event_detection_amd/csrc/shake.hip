@@ -163,7 +163,9 @@ __device__ __forceinline__ void tile_pos(int p, int &ty, int &tx) {
     }
 }
 
-template <int CIN, int N, int CCH, int MODE, int PH, int PW>
+// WN: waves across the N columns (1: every wave has all of them and 64 positions; 2: a wave has every second
+// 32-column tile and 128 positions, so that the weights it reads from L2 feed twice the MFMAs).
+template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN>
 __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const float *__restrict__ x,      // [clip][H][W][CIN]
     const uint4 *__restrict__ wp,     // packed split weights [9*CIN/16][2][N][16], k-step order chunk/tap/k
@@ -174,12 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                                       // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine)
     int H, int W, int tiles_x, int tiles_y, unsigned n_tiles) {
     using G = Conv2dGeom<CIN, N, CCH>;
-    constexpr int NT = G::NT, MT = 2, CO = N / 2;
+    constexpr int NT = G::NT / WN, MT = 2 * WN, CO = N / 2, PWV = 64 * WN;      // NT: column tiles per wave
+    static_assert(G::NT % (2 * WN) == 0 || WN == 1, "a wave needs both halves of the GEMM columns");
     static_assert(MODE != MODE_GATE || CIN == CO, "the gate multiplies the conv input channel by channel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + G::PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    auto colof = [&](int nt) { return col32 + 32 * (wn + WN * nt); };     // GEMM column of the wave's tile nt
     // workgroup b runs on XCD b % 8 and every XCD has its own L2: hand each XCD a contiguous range of
     // tiles so that the tiles it runs back to back are neighbours and share their halos through L2
     const unsigned per_xcd = (gridDim.x + 7) / 8;
@@ -203,42 +208,50 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int ty, tx;
-        tile_pos<PH, PW>(64 * wave + 32 * mt + col32, ty, tx);
+        tile_pos<PH, PW>(PWV * wm + 32 * mt + col32, ty, tx);
         const int off = (ty * G::TW + tx) * G::PSB + 16 * half;
         ah[mt] = plane_h + off;
         al[mt] = plane_l + off;
     }
-    const uint4 *bp = wp + col32 * 2 + half;
+    const uint4 *bp = wp + (col32 + 32 * wn) * 2 + half;
 
     constexpr int POS = (C2_TR + 2) * G::TW;
     constexpr int STAGE_F4 = POS * (CCH / 4);
     constexpr int NLD = (STAGE_F4 + 255) / 256;
-    for (int c = 0; c < G::NCHUNK; ++c) {
-        float4 v[NLD];
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    f32x4v v[NLD];
+    // the clip's input through a buffer descriptor: positions outside the image get an out-of-range offset and
+    // read as zero (the conv's padding) without a branch
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xc), 0, H * W * CIN * 4, 0x00020000);
+    auto load_chunk = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
             const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
             const int yy = ty0 - 1 + pos / G::TW, xx = tx0 - 1 + pos % G::TW;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < STAGE_F4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                v[j] = *reinterpret_cast<const float4 *>(xc + (static_cast<long>(yy) * W + xx) * CIN + c * CCH + ch);
+            const bool ok = i < STAGE_F4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const unsigned off = ok ? static_cast<unsigned>(((yy * W + xx) * CIN + c * CCH + ch) * 4) : 0xfffffff0u;
+            v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
         }
+    };
+    for (int c = 0; c < G::NCHUNK; ++c) {
+        load_chunk(c);
         if (c) __syncthreads();
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + 256 * j;
             const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
             uint2 hi, lo;
-            split2_f16(v[j].x, v[j].y, hi.x, lo.x);
-            split2_f16(v[j].z, v[j].w, hi.y, lo.y);
+            split2_f16(v[j][0], v[j][1], hi.x, lo.x);
+            split2_f16(v[j][2], v[j][3], hi.y, lo.y);
             if (i < STAGE_F4) {
                 *reinterpret_cast<uint2 *>(plane_h + pos * G::PSB + ch * 2) = hi;
                 *reinterpret_cast<uint2 *>(plane_l + pos * G::PSB + ch * 2) = lo;
             }
         }
         __syncthreads();
-        split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (N * 4), N, [](int i) {
+        split_gemm<MT, NT, 9 * G::KS, SPLIT_BDIST, WN>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (N * 4), N, [](int i) {
             const int tap = i / G::KS, ks = i % G::KS;
             return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
         });
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     // ---- epilogue
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float sc = es[col32 + 32 * nt], sh = et[col32 + 32 * nt];
+        const float sc = es[colof(nt)], sh = et[colof(nt)];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -260,12 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int ty, tx;
-                tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
                 const int yy = ty0 + ty, xx = tx0 + tx;
                 if (yy < H && xx < W) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        yc[(static_cast<long>(yy) * W + xx) * N + col32 + 32 * nt] = acc[mt][nt][r];
+                        yc[(static_cast<long>(yy) * W + xx) * N + colof(nt)] = acc[mt][nt][r];
                 }
             }
     } else if constexpr (MODE == MODE_GLU) {
@@ -275,24 +288,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int ty, tx;
-                tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
                 const int yy = ty0 + ty, xx = tx0 + tx;
                 if (yy < H && xx < W) {
 #pragma unroll
                     for (int nt = 0; nt < NT / 2; ++nt)
-                        yc[(static_cast<long>(yy) * W + xx) * CO + col32 + 32 * nt] =
+                        yc[(static_cast<long>(yy) * W + xx) * CO + colof(nt)] =
                             acc[mt][nt][r] * sigmoidf_fast(acc[mt][nt + NT / 2][r]);
                 }
             }
     } else {
-        constexpr int NTC = CO >= 32 ? CO / 32 : 1;        // channel tiles after mixing the branches
+        constexpr int NTC = CO >= 32 ? CO / 32 / WN : 1;   // channel tiles per wave after mixing the branches
         constexpr int WIN = PH * PW;
         const int Ho = H / PH, Wo = W / PW;
         float *yc = y + clip * static_cast<long>(Ho) * Wo * CO;
         const bool lane_ok = CO >= 32 || col32 < CO;
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
-            const int ch = col32 + 32 * nt;
+            const int ch = colof(nt);
             const float b2s = lane_ok ? s2[ch] : 0.f, b2t = lane_ok ? t2[ch] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                     else z2 = __shfl_xor(z1, 16);          // branch 2 of channel c lives in column c + 16
                     const float gate = sigmoidf_fast(alpha * z1 + (1.0f - alpha) * z2);
                     int ty, tx;
-                    tile_pos<PH, PW>(64 * wave + 32 * mt + acc_row(r, half), ty, tx);
+                    tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
                     const int yy = ty0 + ty, xx = tx0 + tx;
                     float uc = 0.f;
                     if constexpr (G::NCHUNK == 1) {
@@ -1053,12 +1066,16 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
     return sc;
 }
 
-template <int CIN, int N, int CCH, int MODE, int PH, int PW>
+// kernels with 128 GEMM columns split them over two waves (gate<64> 3.04 -> 2.74 ms, conv<32,128> 1.56 -> 1.51 ms per
+// 128 clips); requesting the next input chunk before the MFMAs of the current one on top of that gained nothing
+constexpr int C2_WN = 2;
+template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN = 1>
 int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const float *et, float alpha, const float *s2,
                   const float *t2, const float *x, float *y, long n, int H, int W, hipStream_t s) {
     using G = Conv2dGeom<CIN, N, CCH>;
     const int tiles_x = static_cast<int>(sedmi::ceil_div(W, C2_TC)), tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
-    auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW>;
+    if (4.0 * H * W * CIN >= 2147483648.0) return SEDMI_EINVAL;      // one clip's input is addressed with 32-bit offsets
+    auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     const double pos = static_cast<double>(n) * H * W;
@@ -1095,9 +1112,9 @@ int run_shake_cnn(const ShakeCnnDev *m, const float *feats, long n, int T, const
                                                            nullptr, nullptr, sc.y1, sc.u2, nc, T2, 384, s))) return rc;
         if ((rc = launch_conv2d<32, 64, 32, MODE_GATE, 2, 2>("shake_gate<32>", b[1].wb, b[1].es_b, b[1].et_b, alphas[1],
                                                             b[1].s2, b[1].t2, sc.u2, sc.y2, nc, T2, 384, s))) return rc;
-        if ((rc = launch_conv2d<32, 128, 32, MODE_GLU, 1, 1>("shake_conv<32,128>", b[2].wa, b[2].es_a, b[2].et_a, 0.f,
+        if ((rc = launch_conv2d<32, 128, 32, MODE_GLU, 1, 1, C2_WN>("shake_conv<32,128>", b[2].wa, b[2].es_a, b[2].et_a, 0.f,
                                                             nullptr, nullptr, sc.y2, sc.u3, nc, T4, 192, s))) return rc;
-        if ((rc = launch_conv2d<64, 128, 32, MODE_GATE, 1, 2>("shake_gate<64>", b[2].wb, b[2].es_b, b[2].et_b, alphas[2],
+        if ((rc = launch_conv2d<64, 128, 32, MODE_GATE, 1, 2, C2_WN>("shake_gate<64>", b[2].wb, b[2].es_b, b[2].et_b, alphas[2],
                                                              b[2].s2, b[2].t2, sc.u3, seq + c0 * T4 * 6144, nc, T4, 192,
                                                              s))) return rc;
     }
@@ -1609,7 +1626,7 @@ int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, 
             hipLaunchKernelGGL(maxpool_w5_relu_kernel, blocks(rows * (F - 4) * (BR_C / 4)), dim3(256), 0, s, sc.a, sc.b, rows, F);
             SEDMI_CHECK_LAUNCH();
         }
-        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
+        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
                                                               nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 4, s))) return rc;
         {
             sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (2.0 * F - 12));
@@ -1617,7 +1634,7 @@ int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, 
                                F - 4);
             SEDMI_CHECK_LAUNCH();
         }
-        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1], 0.f,
+        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1], 0.f,
                                                               nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 8, s))) return rc;
         {
             sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (F - 8) * 1.25);
