@@ -303,6 +303,46 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
         const int Ho = H / PH, Wo = W / PW;
         float *yc = y + clip * static_cast<long>(Ho) * Wo * CO;
         const bool lane_ok = CO >= 32 || col32 < CO;
+        if constexpr (CO == 16) {
+            // One 32-column tile holds both branches: channel c is column c (branch 1) and column c + 16 (branch
+            // 2), i.e. lanes L and L + 16 hold the two branch values of the same 16 positions.  The pair shares the
+            // work: the low lane finishes the first 8 positions (two pooling windows), the high lane the other 8,
+            // after one exchange of the 8 values the partner needs.
+            static_assert(G::NCHUNK == 1 && WN == 1 && PH == 2 && PW == 2, "the 16-channel gate assumes one staged chunk and 2x2 pooling");
+            const int hi16 = col32 >> 4, ch = col32 & 15;
+            const float b2s = s2[ch], b2t = t2[ch];
+            const float a_own = hi16 ? 1.0f - alpha : alpha, a_oth = hi16 ? alpha : 1.0f - alpha;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float mine[8], theirs[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float lo = acc[mt][0][k], hi = acc[mt][0][k + 8];
+                    mine[k] = hi16 ? hi : lo;
+                    theirs[k] = __shfl_xor(hi16 ? lo : hi, 16);
+                }
+                // position of value k: pb + (k & 3) + 8 * (k >> 2) with pb a multiple of 4 (acc_row(k + 8) = acc_row(k) + 16)
+                int ty, tx;
+                tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half + 16 * hi16, ty, tx);
+                const char *ph0 = plane_h + ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
+                const char *pl0 = plane_l + ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
+#pragma unroll
+                for (int win = 0; win < 2; ++win) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = 4 * win + q;
+                        const float gate = sigmoidf_fast(fmaf(a_own, mine[k], a_oth * theirs[k]));
+                        const int poff = (((q >> 1) & 1) * G::TW + (q & 1) + 4 * win) * G::PSB;
+                        const float uc = static_cast<float>(*reinterpret_cast<const _Float16 *>(ph0 + poff)) +
+                                         static_cast<float>(*reinterpret_cast<const _Float16 *>(pl0 + poff));
+                        sum += fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
+                    }
+                    const int yo = (ty0 + ty) / PH, xo = (tx0 + tx + 4 * win) / PW;
+                    if (yo < Ho && xo < Wo) yc[(static_cast<long>(yo) * Wo + xo) * CO + ch] = sum * 0.25f;
+                }
+            }
+        } else {
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
             const int ch = colof(nt);
@@ -341,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                     }
                 }
             }
+        }
         }
     }
 }
