@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void shake_conv1_split_kernel(const float *
 // ---------------------------------------------------------------------------
 // 3x3 conv as split-f16 implicit GEMM over 8 x 32 position tiles
 // ---------------------------------------------------------------------------
-constexpr int MODE_GLU = 0, MODE_GATE = 1, MODE_BIAS = 2;
+constexpr int MODE_GLU = 0, MODE_GATE = 1, MODE_BIAS = 2, MODE_POOL_NCHW = 3;
 constexpr int C2_TR = 8, C2_TC = 32;
 
 template <int CIN, int N, int CCH>
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     float alpha,                                                     // MODE_GATE: branch mix
     const float *__restrict__ s2, const float *__restrict__ t2,     // MODE_GATE: second BatchNorm affine
     float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2];
-                                      // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine)
+                                      // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine);
+                                      // MODE_POOL_NCHW: [clip][N][H/2][W/2] (the same, max-pooled, ReLU)
     int H, int W, int tiles_x, int tiles_y, unsigned n_tiles) {
     using G = Conv2dGeom<CIN, N, CCH>;
     constexpr int NT = G::NT / WN, MT = 2 * WN, CO = N / 2, PWV = 64 * WN;      // NT: column tiles per wave
@@ -279,6 +280,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         yc[(static_cast<long>(yy) * W + xx) * N + colof(nt)] = acc[mt][nt][r];
+                }
+            }
+    } else if constexpr (MODE == MODE_POOL_NCHW) {
+        // conv + per-column affine, then MaxPool2d(2, 2) + ReLU (models.py:34,55-56) written in the reference's
+        // memory order [clip][chan][H/2][W/2], which the model re-reads as [clip][H/2][chan * W/2] (the reshape at
+        // models.py:59-61 is a reinterpretation, not a permute).  A pooling window is four consecutive accumulator
+        // registers of a lane.
+        static_assert(PH == 2 && PW == 2, "2x2 pooling");
+        const int Ho = H / 2, Wo = W / 2;
+        float *yc = y + clip * static_cast<long>(N) * Ho * Wo;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int ty, tx;
+                tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(4 * w, half), ty, tx);
+                const int yo = (ty0 + ty) / 2, xo = (tx0 + tx) / 2;
+                if (yo < Ho && xo < Wo) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float mx = fmaxf(fmaxf(acc[mt][nt][4 * w], acc[mt][nt][4 * w + 1]),
+                                               fmaxf(acc[mt][nt][4 * w + 2], acc[mt][nt][4 * w + 3]));
+                        yc[(static_cast<long>(colof(nt)) * Ho + yo) * Wo + xo] = fmaxf(mx, 0.f);
+                    }
                 }
             }
     } else if constexpr (MODE == MODE_GLU) {
@@ -1121,7 +1146,7 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     const double pos = static_cast<double>(n) * H * W;
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
-                             pos * 4.0 * (CIN + (MODE == MODE_BIAS ? N : MODE == MODE_GLU ? N / 2.0
+                             pos * 4.0 * (CIN + (MODE == MODE_BIAS ? N : MODE == MODE_POOL_NCHW ? N / 4.0 : MODE == MODE_GLU ? N / 2.0
                                                                                         : CIN + N / 2.0 / (PH * PW))));
     const unsigned n_tiles = static_cast<unsigned>(n * tiles_x * tiles_y);
     hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), G::LDS_BYTES, s, x,
@@ -1675,14 +1700,11 @@ int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, 
                                F - 4);
             SEDMI_CHECK_LAUNCH();
         }
-        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1], 0.f,
-                                                              nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 8, s))) return rc;
-        {
-            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (F - 8) * 1.25);
-            hipLaunchKernelGGL(maxpool2x2_relu_nchw_kernel, blocks(nc * T2 * ((F - 8) / 2) * BR_C), dim3(256), 0, s, sc.a,
-                               sc.seq + c0 * static_cast<long>(T2) * m->K, nc, Ti, F - 8);
-            SEDMI_CHECK_LAUNCH();
-        }
+        // conv3 with MaxPool2d(2, 2) + ReLU and the reference's memory order in its epilogue
+        if ((rc = launch_conv2d<128, 128, 32, MODE_POOL_NCHW, 2, 2, C2_WN>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1],
+                                                                       0.f, nullptr, nullptr, sc.b,
+                                                                       sc.seq + c0 * static_cast<long>(T2) * m->K, nc, Ti,
+                                                                       F - 8, s))) return rc;
     }
     const long grows = n * T2;
     if ((rc = launch_linear("basic_gru_input_proj", m->wih, sc.seq, sc.gi, grows, false, s))) return rc;
