@@ -901,44 +901,66 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *x, const float
 constexpr int BR_C = 128;            // conv channels (models.py:14)
 constexpr int BR_H = 32;             // GRU hidden size (models.py:9)
 
-// conv1: 3x3, 1 -> 128 channels, + bias; x [clip][T][F] -> y [clip][T][F][128].  One thread = one
-// position x 8 channels (K = 9 is too thin for the matrix cores).
-__global__ __launch_bounds__(256) void basic_conv1_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                          const float *__restrict__ bias, float *__restrict__ y,
-                                                          long n_clips, int T, int F) {
+// conv1 (3x3, 1 -> 128 channels, + bias) with MaxPool2d((1, 5), stride 1) + ReLU (models.py:29-30,47-50) in the
+// same pass: x [clip][T][F] -> y [clip][T][F - 4][128].  K = 9 is too thin for the matrix cores.  One thread = 4
+// channels x a run of 12 pooled outputs: it evaluates the conv at the 16 positions the run's windows cover (1.33x
+// the minimum) and slides the maximum over them in registers; the 32 lanes of a half wave are the 32 channel groups
+// of one run, so every store instruction writes 512 contiguous bytes per run position.
+constexpr int BC1_RUN = 12;
+__global__ __launch_bounds__(256) void basic_conv1_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, float *__restrict__ y,
+                                                               long n_rows, int T, int F) {
     __shared__ float wsm[BR_C][10];
     for (int i = threadIdx.x; i < BR_C * 10; i += 256) {
         const int c = i / 10, k = i - c * 10;
         wsm[c][k] = k < 9 ? w[c * 9 + k] : bias[c];
     }
     __syncthreads();
+    const int Wo = F - 4, n_runs = (Wo + BC1_RUN - 1) / BC1_RUN;
     const long idx = blockIdx.x * 256L + threadIdx.x;
-    const long total = n_clips * T * F * (BR_C / 8);
-    if (idx >= total) return;
-    const int cg = static_cast<int>(idx % (BR_C / 8));
-    const long pos = idx / (BR_C / 8);
-    const int f = static_cast<int>(pos % F);
-    const long rest = pos / F;
-    const int t = static_cast<int>(rest % T);
-    const float *xb = x + (rest / T) * static_cast<long>(T) * F;
-    float patch[9];
+    if (idx >= n_rows * n_runs * (BR_C / 4)) return;
+    const int c4 = static_cast<int>(idx % (BR_C / 4));
+    const long rr = idx / (BR_C / 4);
+    const int f0 = static_cast<int>(rr % n_runs) * BC1_RUN;
+    const long row = rr / n_runs;                        // clip * T + t
+    const int t = static_cast<int>(row % T);
+    constexpr int NP = BC1_RUN + 4;                      // conv positions f0 .. f0 + NP - 1
+    float cv[4][NP];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int tt = t - 1 + k / 3, ff = f - 1 + k % 3;
-        patch[k] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? xb[static_cast<long>(tt) * F + ff] : 0.f;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) cv[c][i] = wsm[c4 * 4 + c][9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int tt = t - 1 + ky;
+        const bool row_ok = tt >= 0 && tt < T;
+        const float *xr = x + (row - 1 + ky) * F;       // rows of one clip are consecutive; row_ok keeps it inside the clip
+        float in[NP + 2];
+#pragma unroll
+        for (int i = 0; i < NP + 2; ++i) {
+            const int ff = f0 - 1 + i;
+            in[i] = (row_ok && ff >= 0 && ff < F) ? xr[ff] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float w0 = wsm[c4 * 4 + c][ky * 3], w1 = wsm[c4 * 4 + c][ky * 3 + 1], w2 = wsm[c4 * 4 + c][ky * 3 + 2];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) cv[c][i] = fmaf(in[i + 2], w2, fmaf(in[i + 1], w1, fmaf(in[i], w0, cv[c][i])));
+        }
     }
-    float o[8];
+    // positions past the row's end hold the bias-only value of an all-zero patch or partial sums: they only feed
+    // outputs past Wo, which are not written
+    float *dst = y + (row * Wo + f0) * BR_C + c4 * 4;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float *wr = wsm[cg * 8 + c];
-        float a = wr[9];
+    for (int o = 0; o < BC1_RUN; ++o) {
+        if (f0 + o < Wo) {
+            float m[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a = fmaf(patch[k], wr[k], a);
-        o[c] = a;
+            for (int c = 0; c < 4; ++c)
+                m[c] = fmaxf(fmaxf(fmaxf(fmaxf(cv[c][o], cv[c][o + 1]), fmaxf(cv[c][o + 2], cv[c][o + 3])), cv[c][o + 4]), 0.f);
+            *reinterpret_cast<float4 *>(dst + static_cast<long>(o) * BR_C) = make_float4(m[0], m[1], m[2], m[3]);
+        }
     }
-    float4 *dst = reinterpret_cast<float4 *>(y + pos * BR_C + cg * 8);
-    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
 // MaxPool2d((1, 5), stride 1) + ReLU (models.py:30,49-50): [clip*T][W][128] -> [clip*T][W-4][128]
@@ -960,25 +982,6 @@ __global__ __launch_bounds__(256) void maxpool_w5_relu_kernel(const float *__res
     }
     reinterpret_cast<float4 *>(y + (row * Wo + wo) * BR_C)[c4] =
         make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
-}
-
-// MaxPool2d(2, 2) + ReLU (models.py:34,55-56), written in the reference's memory order
-// [clip][chan][T/2][W/2]: the model then re-reads those bytes as [clip][T/2][chan * W/2]
-// (torch.reshape at models.py:59-61 is a reinterpretation, not a permute).
-__global__ __launch_bounds__(256) void maxpool2x2_relu_nchw_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                   long n_clips, int T, int W) {
-    const int T2 = T / 2, W2 = W / 2;
-    const long idx = blockIdx.x * 256L + threadIdx.x;
-    if (idx >= n_clips * T2 * W2 * BR_C) return;
-    const int c = static_cast<int>(idx % BR_C);        // threads run along channels: coalesced reads
-    const long p = idx / BR_C;
-    const int w2 = static_cast<int>(p % W2);
-    const long q = p / W2;
-    const int t2 = static_cast<int>(q % T2);
-    const long b = q / T2;
-    const float *src = x + ((b * T + 2 * t2) * static_cast<long>(W) + 2 * w2) * BR_C + c;
-    const float m = fmaxf(fmaxf(src[0], src[BR_C]), fmaxf(src[static_cast<long>(W) * BR_C], src[(static_cast<long>(W) + 1) * BR_C]));
-    y[((b * BR_C + c) * static_cast<long>(T2) + t2) * W2 + w2] = fmaxf(m, 0.f);
 }
 
 // GRU(K, 32) recurrence, one direction, + ReLU + Linear(32, n_cls) (models.py:62-65): one wave per
@@ -1682,14 +1685,10 @@ int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, 
         const long nc = std::min<long>(kBasicChunk, n - c0);
         const long rows = nc * Ti;
         {
-            sedmi::ProfileScope prof("basic_conv1", s, 2.0 * 9 * BR_C * rows * F, 4.0 * rows * F * (1.0 + BR_C));
-            hipLaunchKernelGGL(basic_conv1_kernel, blocks(rows * F * (BR_C / 8)), dim3(256), 0, s,
-                               feats + c0 * static_cast<long>(Ti) * F, m->d_w1, m->d_b1, sc.a, nc, Ti, F);
-            SEDMI_CHECK_LAUNCH();
-        }
-        {
-            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (2.0 * F - 4));
-            hipLaunchKernelGGL(maxpool_w5_relu_kernel, blocks(rows * (F - 4) * (BR_C / 4)), dim3(256), 0, s, sc.a, sc.b, rows, F);
+            sedmi::ProfileScope prof("basic_conv1_pool", s, 2.0 * 9 * BR_C * rows * F, 4.0 * rows * (F + (F - 4.0) * BR_C));
+            const long n_runs = sedmi::ceil_div(F - 4, BC1_RUN);
+            hipLaunchKernelGGL(basic_conv1_pool_kernel, blocks(rows * n_runs * (BR_C / 4)), dim3(256), 0, s,
+                               feats + c0 * static_cast<long>(Ti) * F, m->d_w1, m->d_b1, sc.b, rows, Ti, F);
             SEDMI_CHECK_LAUNCH();
         }
         if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
