@@ -23,6 +23,8 @@
 //                                   epilogue, gate with the centre input, BN affine, ReLU, average
 //                                   pool over positions ordered so that a pooling window is a run
 //                                   of accumulator registers of one lane.
+//                        MODE_POOL_W5 / MODE_POOL_NCHW (BasicRCNN): plain conv + affine with the max-pool
+//                                   + ReLU that follows it in the epilogue.
 //   gemm_split_kernel    C = A.B + bias for the GRU input projection (M = clips*T', N = K = 6144).
 //   gru_big_step_kernel  one recurrence step for H = 1024: W_hh (25 MB for both directions) cannot
 //                        live in registers or LDS, so every step streams it from L2 / Infinity
@@ -134,8 +136,10 @@ __global__ __launch_bounds__(256, 2) void shake_conv1_split_kernel(const float *
 // ---------------------------------------------------------------------------
 // 3x3 conv as split-f16 implicit GEMM over 8 x 32 position tiles
 // ---------------------------------------------------------------------------
-constexpr int MODE_GLU = 0, MODE_GATE = 1, MODE_BIAS = 2, MODE_POOL_NCHW = 3;
+constexpr int MODE_GLU = 0, MODE_GATE = 1, MODE_BIAS = 2, MODE_POOL_NCHW = 3, MODE_POOL_W5 = 4;
 constexpr int C2_TR = 8, C2_TC = 32;
+// columns a tile advances by: a (1,5) pooling window needs 4 more conv columns than it yields outputs
+__host__ __device__ constexpr int c2_xstride(int mode) { return mode == MODE_POOL_W5 ? C2_TC - 4 : C2_TC; }
 
 template <int CIN, int N, int CCH>
 struct Conv2dGeom {
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const float *__restrict__ s2, const float *__restrict__ t2,     // MODE_GATE: second BatchNorm affine
     float *__restrict__ y,            // MODE_GLU: [clip][H][W][N/2]; MODE_GATE: [clip][H/PH][W/PW][N/2];
                                       // MODE_BIAS: [clip][H][W][N] (plain conv + per-column affine);
-                                      // MODE_POOL_NCHW: [clip][N][H/2][W/2] (the same, max-pooled, ReLU)
+                                      // MODE_POOL_NCHW: [clip][N][H/2][W/2] (the same, max-pooled, ReLU);
+                                      // MODE_POOL_W5: [clip][H][W-4][N] (the same, (1,5) max-pooled, ReLU)
     int H, int W, int tiles_x, int tiles_y, unsigned n_tiles) {
     using G = Conv2dGeom<CIN, N, CCH>;
     constexpr int NT = G::NT / WN, MT = 2 * WN, CO = N / 2, PWV = 64 * WN;      // NT: column tiles per wave
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const unsigned per_xcd = (gridDim.x + 7) / 8;
     int bid = static_cast<int>((blockIdx.x % 8) * per_xcd + blockIdx.x / 8);
     if (static_cast<unsigned>(bid) >= n_tiles) return;
-    const int tx0 = (bid % tiles_x) * C2_TC;
+    const int tx0 = (bid % tiles_x) * c2_xstride(MODE);
     bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * C2_TR;
     const long clip = bid / tiles_y;
@@ -282,6 +287,45 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                         yc[(static_cast<long>(yy) * W + xx) * N + colof(nt)] = acc[mt][nt][r];
                 }
             }
+    } else if constexpr (MODE == MODE_POOL_W5) {
+        // conv + per-column affine, then MaxPool2d((1, 5), stride 1) + ReLU (models.py:32,52-53): y [clip][H][W - 4][N].
+        // A tile yields 28 pooled columns from its 32 conv columns.  An m-tile is one row of 32 columns; a lane
+        // holds 4 groups of 4 consecutive columns (8j + 4 * half + q), its partner (lane ^ 32) the groups in
+        // between.  A lane finishes the windows that START in its own groups: they end in the partner's next group,
+        // which is the partner's group j (half 0) or j + 1 (half 1) -- the partner sends exactly that.
+        static_assert(PH == 1 && PW == 1, "row-wise pooling");
+        const int Wo = W - 4;
+        float *yc = y + clip * static_cast<long>(H) * Wo * N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int ty, tx;
+            tile_pos<PH, PW>(PWV * wm + 32 * mt, ty, tx);          // tx = 0: an m-tile is one tile row
+            const int yy = ty0 + ty;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float *dst = yc + (static_cast<long>(yy) * Wo + tx0 + 4 * half) * N + colof(nt);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float own[4], nxt[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        own[q] = acc[mt][nt][4 * j + q];
+                        // what the partner needs from this lane: its group j if this lane is half 1, else group j + 1
+                        const float send = half ? own[q] : acc[mt][nt][j < 3 ? 4 * (j + 1) + q : 4 * j + q];
+                        nxt[q] = __shfl_xor(send, 32);
+                    }
+                    const float s3 = own[3], s2 = fmaxf(own[2], s3), s1 = fmaxf(own[1], s2), s0 = fmaxf(own[0], s1);
+                    const float p0 = nxt[0], p1 = fmaxf(p0, nxt[1]), p2 = fmaxf(p1, nxt[2]), p3 = fmaxf(p2, nxt[3]);
+                    const float o[4] = {fmaxf(fmaxf(s0, p0), 0.f), fmaxf(fmaxf(s1, p1), 0.f), fmaxf(fmaxf(s2, p2), 0.f),
+                                        fmaxf(fmaxf(s3, p3), 0.f)};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int txo = 8 * j + 4 * half + q;          // pooled column inside the tile
+                        if (yy < H && txo < C2_TC - 4 && tx0 + txo < Wo) dst[static_cast<long>(8 * j + q) * N] = o[q];
+                    }
+                }
+            }
+        }
     } else if constexpr (MODE == MODE_POOL_NCHW) {
         // conv + per-column affine, then MaxPool2d(2, 2) + ReLU (models.py:34,55-56) written in the reference's
         // memory order [clip][chan][H/2][W/2], which the model re-reads as [clip][H/2][chan * W/2] (the reshape at
@@ -963,27 +1007,6 @@ __global__ __launch_bounds__(256) void basic_conv1_pool_kernel(const float *__re
     }
 }
 
-// MaxPool2d((1, 5), stride 1) + ReLU (models.py:30,49-50): [clip*T][W][128] -> [clip*T][W-4][128]
-__global__ __launch_bounds__(256) void maxpool_w5_relu_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                              long n_rows, int W) {
-    const int Wo = W - 4;
-    const long idx = blockIdx.x * 256L + threadIdx.x;
-    if (idx >= n_rows * Wo * (BR_C / 4)) return;
-    const int c4 = static_cast<int>(idx % (BR_C / 4));
-    const long p = idx / (BR_C / 4);
-    const int wo = static_cast<int>(p % Wo);
-    const long row = p / Wo;
-    const float4 *src = reinterpret_cast<const float4 *>(x + (row * W + wo) * BR_C) + c4;
-    float4 m = src[0];
-#pragma unroll
-    for (int k = 1; k < 5; ++k) {
-        const float4 v = src[k * (BR_C / 4)];
-        m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
-    }
-    reinterpret_cast<float4 *>(y + (row * Wo + wo) * BR_C)[c4] =
-        make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
-}
-
 // GRU(K, 32) recurrence, one direction, + ReLU + Linear(32, n_cls) (models.py:62-65): one wave per
 // clip.  gi [clip*T2][128] holds W_ih x + b_ih (+ b_hh for r, z) in columns 0..95.
 __global__ __launch_bounds__(64) void basic_gru_head_kernel(const float *__restrict__ gi, const float *__restrict__ whh,
@@ -1142,14 +1165,15 @@ template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN = 1>
 int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const float *et, float alpha, const float *s2,
                   const float *t2, const float *x, float *y, long n, int H, int W, hipStream_t s) {
     using G = Conv2dGeom<CIN, N, CCH>;
-    const int tiles_x = static_cast<int>(sedmi::ceil_div(W, C2_TC)), tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
+    const int tiles_x = static_cast<int>(MODE == MODE_POOL_W5 ? sedmi::ceil_div(W - 4, C2_TC - 4) : sedmi::ceil_div(W, C2_TC));
+    const int tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
     if (4.0 * H * W * CIN >= 2147483648.0) return SEDMI_EINVAL;      // one clip's input is addressed with 32-bit offsets
     auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     const double pos = static_cast<double>(n) * H * W;
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
-                             pos * 4.0 * (CIN + (MODE == MODE_BIAS ? N : MODE == MODE_POOL_NCHW ? N / 4.0 : MODE == MODE_GLU ? N / 2.0
+                             pos * 4.0 * (CIN + (MODE == MODE_BIAS || MODE == MODE_POOL_W5 ? N : MODE == MODE_POOL_NCHW ? N / 4.0 : MODE == MODE_GLU ? N / 2.0
                                                                                         : CIN + N / 2.0 / (PH * PW))));
     const unsigned n_tiles = static_cast<unsigned>(n * tiles_x * tiles_y);
     hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), G::LDS_BYTES, s, x,
@@ -1691,17 +1715,12 @@ int sedmi_basic_rcnn_forward_f32(const sedmi_basic_rcnn *m, const float *feats, 
                                feats + c0 * static_cast<long>(Ti) * F, m->d_w1, m->d_b1, sc.b, rows, Ti, F);
             SEDMI_CHECK_LAUNCH();
         }
-        if ((rc = launch_conv2d<128, 128, 32, MODE_BIAS, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
-                                                              nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 4, s))) return rc;
-        {
-            sedmi::ProfileScope prof("basic_maxpool", s, 0.0, 4.0 * rows * BR_C * (2.0 * F - 12));
-            hipLaunchKernelGGL(maxpool_w5_relu_kernel, blocks(rows * (F - 8) * (BR_C / 4)), dim3(256), 0, s, sc.a, sc.b, rows,
-                               F - 4);
-            SEDMI_CHECK_LAUNCH();
-        }
+        // conv2 with its (1,5) max-pool + ReLU in the epilogue
+        if ((rc = launch_conv2d<128, 128, 32, MODE_POOL_W5, 1, 1, C2_WN>("basic_conv<128,128>", m->d_wc[0], m->d_es[0], m->d_et[0], 0.f,
+                                                                 nullptr, nullptr, sc.b, sc.a, nc, Ti, F - 4, s))) return rc;
         // conv3 with MaxPool2d(2, 2) + ReLU and the reference's memory order in its epilogue
         if ((rc = launch_conv2d<128, 128, 32, MODE_POOL_NCHW, 2, 2, C2_WN>("basic_conv<128,128>", m->d_wc[1], m->d_es[1], m->d_et[1],
-                                                                       0.f, nullptr, nullptr, sc.b,
+                                                                       0.f, nullptr, nullptr, sc.a,
                                                                        sc.seq + c0 * static_cast<long>(T2) * m->K, nc, Ti,
                                                                        F - 8, s))) return rc;
     }

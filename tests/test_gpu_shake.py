@@ -208,3 +208,19 @@ def test_gemm_rows_cross_a_tile_boundary_vs_oracle(model, tmodel):
     sd = synth.synth_shake_state_dict(synth.shake_transformer_state_dict_spec(10), 0)
     np.testing.assert_allclose(tmodel(x.cuda(), al).cpu().numpy(), shake.shake_transformer_forward(sd, x, al).numpy(),
                                rtol=0, atol=ATOL_LOGITS)
+
+
+def test_basic_rcnn_wide_input_odd_length_vs_oracle():
+    # 128 bins: conv1 runs end in a partial one (124 = 10 * 12 + 4), conv2 yields 120 pooled columns over five
+    # 28-column tiles (the last one partial); 11 frames: the last row has no pooling partner
+    from oracle import shake
+    from sound_event_detection_amd.models import BasicRCNN
+    sd = synth.synth_shake_state_dict(synth.basic_rcnn_state_dict_spec(6, 128), 5)
+    m = BasicRCNN(6, 128)
+    m.load_state_dict(sd)
+    m = m.eval().cuda()
+    x = torch.from_numpy(synth.synth_shake_feats(21, 2, 11, 128))
+    want = shake.basic_rcnn_forward(sd, x).numpy()
+    got = m(x.cuda()).cpu().numpy()
+    assert got.shape == want.shape == (2, 5, 6)
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
