@@ -266,7 +266,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     // ---- epilogue
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float sc = es[colof(nt)], sh = et[colof(nt)];
+        float sc = es[colof(nt)], sh = et[colof(nt)];
+        if constexpr (MODE == MODE_GATE) {
+            // the gate is sigmoid(a x1 + (1 - a) x2) = 1 / (1 + exp2(-log2(e) (a x1 + (1 - a) x2))): the branch weight
+            // and the exponent factor go into the column's affine, the epilogue adds the two and calls exp2
+            const bool first = CO >= 32 ? nt < NT / 2 : col32 < CO;
+            const float f = -1.4426950408889634f * (first ? alpha : 1.0f - alpha);
+            sc *= f;
+            sh *= f;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -380,7 +388,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
             static_assert(G::NCHUNK == 1 && WN == 1 && PH == 2 && PW == 2, "the 16-channel gate assumes one staged chunk and 2x2 pooling");
             const int hi16 = col32 >> 4, ch = col32 & 15;
             const float b2s = s2[ch], b2t = t2[ch];
-            const float a_own = hi16 ? 1.0f - alpha : alpha, a_oth = hi16 ? alpha : 1.0f - alpha;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float mine[8], theirs[8];
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int k = 4 * win + q;
-                        const float gate = sigmoidf_fast(fmaf(a_own, mine[k], a_oth * theirs[k]));
+                        const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mine[k] + theirs[k]));
                         const int poff = (((q >> 1) & 1) * G::TW + (q & 1) + 4 * win) * G::PSB;
                         const float uc = static_cast<float>(*reinterpret_cast<const _Float16 *>(ph0 + poff)) +
                                          static_cast<float>(*reinterpret_cast<const _Float16 *>(pl0 + poff));
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                     float z2;
                     if constexpr (CO >= 32) z2 = acc[mt][nt + NTC][r];
                     else z2 = __shfl_xor(z1, 16);          // branch 2 of channel c lives in column c + 16
-                    const float gate = sigmoidf_fast(alpha * z1 + (1.0f - alpha) * z2);
+                    const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z1 + z2));
                     int ty, tx;
                     tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
                     const int yy = ty0 + ty, xx = tx0 + tx;
