@@ -274,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
             const float f = -1.4426950408889634f * (first ? alpha : 1.0f - alpha);
             sc *= f;
             sh *= f;
+        } else if constexpr (MODE == MODE_GLU) {
+            if (nt >= NT / 2) {          // the GLU's gate half: sigmoid(x) = 1 / (1 + exp2(-log2(e) x))
+                sc *= -1.4426950408889634f;
+                sh *= -1.4426950408889634f;
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
 #pragma unroll
                     for (int nt = 0; nt < NT / 2; ++nt)
                         yc[(static_cast<long>(yy) * W + xx) * CO + colof(nt)] =
-                            acc[mt][nt][r] * sigmoidf_fast(acc[mt][nt + NT / 2][r]);
+                            acc[mt][nt][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt + NT / 2][r]));
                 }
             }
     } else {
