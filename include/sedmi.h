@@ -333,6 +333,29 @@ int sedmi_decode_events(const float *p, int64_t total_frames, int n_class,
                         int64_t capacity, int64_t *n_events, void *ws, size_t ws_bytes,
                         void *stream);
 
+/* Allocation-free variant of sedmi_decode_events.  It has no counterpart in the
+ * reference; it exists for callers that cannot allocate device memory or hand
+ * over a workspace: code running under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same arguments, results and ordering as
+ * sedmi_decode_events minus `ws` / `ws_bytes`: the per-(recording, class)
+ * counters and offsets live in a static device array inside the library
+ * (about 770 KB per GPU, held until the process ends).  The call allocates
+ * nothing, on the host side of the runtime or on the device, and records no
+ * profiling events.
+ *   - n_seg * n_class must not exceed SEDMI_DECODE_STATIC_MAX_PAIRS
+ *     (SEDMI_EINVAL beyond it);
+ *   - the array's device address is looked up on the first call on each
+ *     device (hipGetSymbolAddress): make that first call outside graph capture;
+ *   - all calls on one GPU share the array: calls that overlap on one GPU
+ *     (different streams or threads) race on it and must be serialised by the
+ *     caller.  Nothing in it needs clearing between calls. */
+#define SEDMI_DECODE_STATIC_MAX_PAIRS 65536
+int sedmi_decode_events_static(const float *p, int64_t total_frames, int n_class,
+                               const int64_t *seg_start, const int64_t *seg_cutoff, int64_t n_seg,
+                               float thr, int apply_sigmoid, int median_win,
+                               int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off,
+                               int64_t capacity, int64_t *n_events, void *stream);
+
 /* Per-class confusion counts of thresholded predictions against 0/1 labels —
  * the sufficient statistics of the sklearn scores in evaluate()
  * (evaluation.py:26-45).  labels: device float32 [n_rows, n_class] (the

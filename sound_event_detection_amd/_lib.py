@@ -117,6 +117,8 @@ SIGNATURES = {
     "sedmi_decode_workspace_bytes": (_SZ, [_I64, _I]),
     "sedmi_decode_events": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,
                                  _I64, _VP, _VP, _SZ, _VP]),
+    "sedmi_decode_events_static": (_I, [_VP, _I64, _I, _VP, _VP, _I64, _F, _I, _I, _VP, _VP, _VP, _VP,
+                                        _I64, _VP, _VP]),
     "sedmi_confusion_counts": (_I, [_VP, _VP, _I64, _I, _F, _I, _VP, _VP]),
     "sedmi_profile_enable": (_I, [_I]),
     "sedmi_profile_collect": (_I, [C.POINTER(KernelStat), _I]),

@@ -17,6 +17,8 @@
 // and every lane sums its window from there.
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int kMaxHalf = 64;                 // median window <= 129
@@ -156,6 +158,35 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float *p, const fl
 
 }  // namespace
 
+// Library-owned scratch of sedmi_decode_events_static: counters (int) and offsets (int64) for up to
+// SEDMI_DECODE_STATIC_MAX_PAIRS (recording, class) pairs, laid out as decode_launch expects.  Every GPU
+// the library runs on holds its own copy of this array until the process ends.
+constexpr size_t kStaticScratchBytes =
+    (SEDMI_DECODE_STATIC_MAX_PAIRS * sizeof(int) + 255) / 256 * 256 +
+    (SEDMI_DECODE_STATIC_MAX_PAIRS * sizeof(long long) + 255) / 256 * 256 + 256;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+// Device address of `scratch` on the current device.  In host code the array's name is only a handle for
+// the runtime's symbol table, never a device address: the address is looked up once per device (with that
+// device current) and kept; every use of the array's memory from the host goes through it.
+static int static_scratch_address(void **out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mutex;
+    static void *dev_ptr[kMaxDevices] = {nullptr};
+    int dev = -1;
+    SEDMI_CHECK_HIP(hipGetDevice(&dev));
+    SEDMI_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d outside [0, %d)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(mutex);
+    if (dev_ptr[dev] == nullptr) {
+        void *ptr = nullptr;
+        SEDMI_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        SEDMI_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
+        dev_ptr[dev] = ptr;
+    }
+    *out = dev_ptr[dev];
+    return SEDMI_OK;
+}
+
 extern "C" {
 
 int sedmi_threshold_i64(const float *p, int64_t n, float thr, int apply_sigmoid, int64_t *out, void *stream) {
@@ -175,55 +206,101 @@ size_t sedmi_decode_workspace_bytes(int64_t n_seg, int n_class) {
     return sedmi::align_up(pairs * sizeof(int), 256) + sedmi::align_up(pairs * sizeof(long long), 256) + 256;
 }
 
-int sedmi_decode_events(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
-                        const int64_t *seg_cutoff, int64_t n_seg, float thr, int apply_sigmoid,
-                        int median_win, int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off,
-                        int64_t capacity, int64_t *n_events, void *ws, size_t ws_bytes, void *stream) {
+// Argument checks shared by both decode entry points (everything but the scratch).
+static int decode_check(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
+                        const int64_t *seg_cutoff, int64_t n_seg, int median_win, int32_t *ev_seg,
+                        int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off, int64_t capacity, int64_t *n_events) {
     SEDMI_REQUIRE(n_class > 0 && n_seg >= 0 && total_frames >= 0 && capacity >= 0, "bad shape");
     SEDMI_REQUIRE(median_win >= 1 && (median_win & 1) && median_win <= 2 * kMaxHalf + 1,
                   "median window must be odd and in [1, %d] (got %d)", 2 * kMaxHalf + 1, median_win);
     SEDMI_REQUIRE(total_frames < (1LL << 31), "more than 2^31 frames in one call");
     SEDMI_REQUIRE(n_events != nullptr, "n_events is null");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_seg == 0) {
-        SEDMI_CHECK_HIP(hipMemsetAsync(n_events, 0, sizeof(int64_t), s));
-        return SEDMI_OK;
-    }
+    if (n_seg == 0) return SEDMI_OK;
     SEDMI_REQUIRE(p || total_frames == 0, "null probability pointer");
     SEDMI_REQUIRE(seg_start && seg_cutoff, "null segment table");
     SEDMI_REQUIRE(capacity == 0 || (ev_seg && ev_cls && ev_on && ev_off), "null event buffer");
-    SEDMI_REQUIRE(ws && ws_bytes >= sedmi_decode_workspace_bytes(n_seg, n_class),
-                  "decode workspace too small: need %zu bytes", sedmi_decode_workspace_bytes(n_seg, n_class));
+    return SEDMI_OK;
+}
+
+// count pass -> exclusive scan -> write pass; `scratch` holds the per-(recording, class) counters
+// (int) followed, 256-byte aligned, by their scanned offsets (int64).  `timed` = bracket the launches
+// with profiling events when profiling is on (creating events allocates, so the allocation-free entry
+// point passes false).
+static int decode_launch(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
+                         const int64_t *seg_cutoff, int64_t n_seg, float thr, int apply_sigmoid, int median_win,
+                         int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off, int64_t capacity,
+                         int64_t *n_events, void *scratch, bool timed, hipStream_t s) {
     const long pairs = static_cast<long>(n_seg) * n_class;
-    int *counts = static_cast<int *>(ws);
-    long long *offsets = reinterpret_cast<long long *>(static_cast<char *>(ws) +
+    int *counts = static_cast<int *>(scratch);
+    long long *offsets = reinterpret_cast<long long *>(static_cast<char *>(scratch) +
                                                        sedmi::align_up(pairs * sizeof(int), 256));
     const unsigned grid = static_cast<unsigned>(sedmi::ceil_div(pairs, kWavesPerBlock));
     const int half = median_win / 2;
     const long long *ss = reinterpret_cast<const long long *>(seg_start);
     const long long *sc = reinterpret_cast<const long long *>(seg_cutoff);
     const double dbytes = 4.0 * total_frames * n_class;
-    {
-    sedmi::ProfileScope prof("decode_count", s, 0.0, dbytes);
+    timed = timed && sedmi::profile_enabled();
+    if (timed) sedmi::profile_begin("decode_count", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));
-    }
+    if (timed) sedmi::profile_end(s);
     SEDMI_CHECK_LAUNCH();
-    {
-    sedmi::ProfileScope prof("decode_scan", s, 0.0, 12.0 * pairs);
+    if (timed) sedmi::profile_begin("decode_scan", s, 0.0, 12.0 * pairs);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, counts, pairs, offsets,
                        reinterpret_cast<long long *>(n_events));
-    }
+    if (timed) sedmi::profile_end(s);
     SEDMI_CHECK_LAUNCH();
-    {
-    sedmi::ProfileScope prof("decode_write", s, 0.0, dbytes);
+    if (timed) sedmi::profile_begin("decode_write", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));
-    }
+    if (timed) sedmi::profile_end(s);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
+}
+
+int sedmi_decode_events(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
+                        const int64_t *seg_cutoff, int64_t n_seg, float thr, int apply_sigmoid,
+                        int median_win, int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off,
+                        int64_t capacity, int64_t *n_events, void *ws, size_t ws_bytes, void *stream) {
+    const int rc = decode_check(p, total_frames, n_class, seg_start, seg_cutoff, n_seg, median_win, ev_seg, ev_cls,
+                                ev_on, ev_off, capacity, n_events);
+    if (rc != SEDMI_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_seg == 0) {
+        SEDMI_CHECK_HIP(hipMemsetAsync(n_events, 0, sizeof(int64_t), s));
+        return SEDMI_OK;
+    }
+    SEDMI_REQUIRE(ws && ws_bytes >= sedmi_decode_workspace_bytes(n_seg, n_class),
+                  "decode workspace too small: need %zu bytes", sedmi_decode_workspace_bytes(n_seg, n_class));
+    return decode_launch(p, total_frames, n_class, seg_start, seg_cutoff, n_seg, thr, apply_sigmoid, median_win,
+                         ev_seg, ev_cls, ev_on, ev_off, capacity, n_events, ws, true, s);
+}
+
+int sedmi_decode_events_static(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
+                               const int64_t *seg_cutoff, int64_t n_seg, float thr, int apply_sigmoid,
+                               int median_win, int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on,
+                               int32_t *ev_off, int64_t capacity, int64_t *n_events, void *stream) {
+    const int rc = decode_check(p, total_frames, n_class, seg_start, seg_cutoff, n_seg, median_win, ev_seg, ev_cls,
+                                ev_on, ev_off, capacity, n_events);
+    if (rc != SEDMI_OK) return rc;
+    SEDMI_REQUIRE(n_seg <= SEDMI_DECODE_STATIC_MAX_PAIRS / n_class,
+                  "sedmi_decode_events_static: %lld recordings x %d classes exceeds the static scratch of %d "
+                  "(recording, class) pairs; use sedmi_decode_events with a workspace",
+                  static_cast<long long>(n_seg), n_class, SEDMI_DECODE_STATIC_MAX_PAIRS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_seg == 0) {
+        SEDMI_CHECK_HIP(hipMemsetAsync(n_events, 0, sizeof(int64_t), s));
+        return SEDMI_OK;
+    }
+    void *scratch_dev = nullptr;
+    const int rs = static_scratch_address(&scratch_dev);
+    if (rs != SEDMI_OK) return rs;
+    // nothing in the scratch has to start at zero: the count pass writes counts[0 .. pairs) and the scan
+    // writes offsets[0 .. pairs) before the write pass reads either
+    return decode_launch(p, total_frames, n_class, seg_start, seg_cutoff, n_seg, thr, apply_sigmoid, median_win,
+                         ev_seg, ev_cls, ev_on, ev_off, capacity, n_events, scratch_dev, false, s);
 }
 
 int sedmi_confusion_counts(const float *p, const float *labels, int64_t n_rows, int n_class, float thr,
