@@ -133,12 +133,21 @@ typedef struct sedmi_crnn_weights {
  * layout its kernel reads, and uploads the result to the current device. */
 int sedmi_crnn_create(sedmi_crnn **model, const sedmi_crnn_weights *w);
 int sedmi_crnn_destroy(sedmi_crnn *model);
-/* Arithmetic of the conv blocks 1..6 (block 0, the GRU and the head are always float32):
- *   SEDMI_PRECISION_F32        v_mfma_f32_32x32x2_f32, exact float32 products;
- *   SEDMI_PRECISION_SPLIT_F16  every float32 operand split into two f16 halves (22 significand
+/* Arithmetic of the whole model's contractions (all seven conv blocks, the GRU input projections
+ * and the recurrence; the strong head is always float32):
+ *   SEDMI_PRECISION_F32        v_mfma_f32_32x32x2_f32 / float32 FMAs, exact float32 products;
+ *   SEDMI_PRECISION_SPLIT_F16  every float32 operand split into two f16 halves (21-22 significand
  *                              bits), three f16 MFMAs per product, float32 accumulation: about
  *                              4x the relative rounding of float32 at ~5x the matrix-core rate.
- *                              Activations of magnitude >= 65504 saturate in this mode.
+ * Range in SPLIT_F16 mode.  The input features (block 0 reads the raw power mel spectrogram, whose
+ * magnitude follows the audio level squared) may have ANY float32 magnitude: each clip is scaled by
+ * an exact power of two to max |x| in [2^13, 2^14) before it is split, and the factor is undone
+ * exactly behind the matrix product, so int16-scale PCM, loud recordings at n_fft 4096 or very quiet
+ * ones lose nothing.  Activations between the layers are split as they are: a value of magnitude
+ * >= 65504 there saturates.  With BatchNorm statistics that belong to the features being fed (any
+ * trained checkpoint on its own data) they are O(1..100); a checkpoint evaluated on features many
+ * orders of magnitude louder than it was trained on can exceed the range -- use SEDMI_PRECISION_F32
+ * for that (the reference's float32 path has no such limit).
  * The default is SEDMI_PRECISION_SPLIT_F16. */
 #define SEDMI_PRECISION_F32        0
 #define SEDMI_PRECISION_SPLIT_F16  1
@@ -208,8 +217,9 @@ int sedmi_shake_rcnn_destroy(sedmi_shake_rcnn *model);
 /* Device scratch needed for n_clips clips of T frames x 768 bins (0 on bad input). */
 size_t sedmi_shake_rcnn_workspace_bytes(const sedmi_shake_rcnn *model, int64_t n_clips, int64_t T);
 
-/* feats [n_clips, T, 768] (device) -> logits [n_clips, T/4, n_class] (device);
- * T must be a multiple of 4.  alphas: three HOST floats, the ShakeShake mixing
+/* feats [n_clips, T, 768] (device) -> logits [n_clips, T/4, n_class] (device),
+ * T/4 floored as the reference's three AvgPool2d stages floor odd sizes
+ * (models.py:109-111: 1001 frames -> 500 -> 250 -> 250).  alphas: three HOST floats, the ShakeShake mixing
  * weights of cnn1..cnn3; the reference draws each with torch.rand(1) on every
  * eval-mode forward (models.py:88-91), so the caller supplies them (draw them
  * the same way to reproduce the reference's stream, or pass 0.5 for the
@@ -263,7 +273,7 @@ int sedmi_shake_transformer_destroy(sedmi_shake_transformer *model);
 size_t sedmi_shake_transformer_workspace_bytes(const sedmi_shake_transformer *model, int64_t n_clips, int64_t T);
 
 /* feats [n_clips, T, 768] (device) -> logits [n_clips, T/4, n_class] (device);
- * T a multiple of 4; alphas as for sedmi_shake_rcnn_forward_f32. */
+ * T/4 floored; alphas as for sedmi_shake_rcnn_forward_f32. */
 int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *model, const float *feats,
                                         int64_t n_clips, int64_t T, const float *alphas, float *logits,
                                         void *ws, size_t ws_bytes, void *stream);

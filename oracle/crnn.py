@@ -12,8 +12,9 @@ primitives the reference's modules resolve to:
   branch at :146-156 only feeds the weak output that forward() drops at :268.
 
 Pinned against the imported reference classes for the conv stack and the GRU
-(tests/golden/crnn_*.npz, written by oracle/make_golden.py); the glue is
-restated only (nnet/CRNN.py needs torchaudio to import).
+(tests/golden/crnn_seed*.npz) and against outputs of the reference's
+CRNN.forward itself for 1, 6, 10 and 92 classes (tests/golden/crnn_forward.npz),
+all written by oracle/make_golden.py.
 """
 from __future__ import annotations
 

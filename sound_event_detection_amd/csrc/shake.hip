@@ -1436,7 +1436,6 @@ inline int seq_kmap(int k) { return (k % 64) * 96 + k / 64; }
 int shake_check(const void *m, int64_t n, int64_t T) {
     SEDMI_REQUIRE(m != nullptr, "model is null");
     SEDMI_REQUIRE(n >= 0 && T >= 0 && T < (1 << 24) && n < (1LL << 31), "bad shape");
-    SEDMI_REQUIRE(T % 4 == 0, "T = %lld: the three pooling stages need a multiple of 4 frames", static_cast<long long>(T));
     return SEDMI_OK;
 }
 
@@ -1509,7 +1508,7 @@ int sedmi_shake_cnn_f32(const sedmi_shake_rcnn *m, const float *feats, int64_t n
                         float *seq_ref_order, void *ws, size_t ws_bytes, void *stream) {
     int rc = shake_check(m, n, T);
     if (rc) return rc;
-    if (n == 0 || T == 0) return SEDMI_OK;
+    if (n == 0 || T < 4) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && seq_ref_order && ws, "null pointer");
     ShakeScratch sc = carve_shake(ws, n, T, SHAKE_RCNN);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
@@ -1526,7 +1525,7 @@ int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *m, const float *feats, 
                                  const float *alphas, float *logits, void *ws, size_t ws_bytes, void *stream) {
     int rc = shake_check(m, n, T);
     if (rc) return rc;
-    if (n == 0 || T == 0) return SEDMI_OK;
+    if (n == 0 || T < 4) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
     ShakeScratch sc = carve_shake(ws, n, T, SHAKE_RCNN);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
@@ -1603,7 +1602,7 @@ int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const 
                                         const float *alphas, float *logits, void *ws, size_t ws_bytes, void *stream) {
     int rc = shake_check(m, n, T);
     if (rc) return rc;
-    if (n == 0 || T == 0) return SEDMI_OK;
+    if (n == 0 || T < 4) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
     SEDMI_REQUIRE(n <= 65535, "at most 65535 clips per call");
     ShakeScratch sc = carve_shake(ws, n, T, SHAKE_TRANSFORMER);

@@ -218,7 +218,7 @@ def extract_mel_spectrograms(audio_files, dataset_location, dataset, clip_length
             if len(clip) < n_clip:                       # zero-pad the last piece (:41-42)
                 clip = np.concatenate([clip, np.zeros(n_clip - len(clip), np.float32)])
             keys.append((i, audio_file))
-            pending.append(clip)
+            pending.append(clip[:n_clip])          # a loader may round a fractional sample count up
             if len(pending) >= batch_clips:
                 flush()
     flush()

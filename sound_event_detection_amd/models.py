@@ -79,6 +79,25 @@ class BasicRCNN(nn.Module):
         self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_basic_rcnn_destroy, handle)
         return handle
 
+    # ---- what pipeline.SedPipeline needs from a model: output kind, shapes, and a forward into given buffers
+    returns_logits = True               # the caller applies the sigmoid (training.py:358)
+    time_pooling = 2
+
+    @property
+    def n_outputs(self):
+        return self.num_classes
+
+    @property
+    def feature_width(self):
+        return self.frequency_dim
+
+    def _workspace_bytes(self, handle, B, T):
+        return _lib.lib().sedmi_basic_rcnn_workspace_bytes(handle, B, T)
+
+    def _forward_into(self, handle, x_ptr, B, T, out, ws, ws_bytes, stream, alphas=None):
+        _lib.check(_lib.lib().sedmi_basic_rcnn_forward_f32(handle, x_ptr, B, T, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                                           stream), "sedmi_basic_rcnn_forward_f32")
+
     def forward(self, x):
         if self.training:
             raise RuntimeError("inference-only model: call model.eval() first")
@@ -159,6 +178,25 @@ class _ShakeBase(nn.Module):
             w.bn2_w[i], w.bn2_b[i] = p(b + "bn2.weight"), p(b + "bn2.bias")
             w.bn2_mean[i], w.bn2_var[i] = p(b + "bn2.running_mean"), p(b + "bn2.running_var")
 
+    returns_logits = True               # the caller applies the sigmoid (training.py:358)
+    time_pooling = 4
+    feature_width = N_BINS
+
+    @property
+    def n_outputs(self):
+        return self.num_classes
+
+    @staticmethod
+    def draw_alphas(alphas=None):
+        """Three ShakeShake mixing weights as a C float array: the given ones, or three
+        ``torch.rand(1)`` draws from the CPU generator in block order (models.py:91)."""
+        if alphas is None:
+            alphas = [float(torch.rand(1)) for _ in range(3)]
+        alphas = [float(a) for a in alphas]
+        if len(alphas) != 3:
+            raise ValueError("alphas: one ShakeShake mixing weight per block (3)")
+        return (C.c_float * 3)(*alphas)
+
     def _prepare(self, x, alphas):
         if self.training:
             raise RuntimeError("inference-only model: call model.eval() first")
@@ -166,14 +204,7 @@ class _ShakeBase(nn.Module):
             raise _lib.SedmiError("forward needs a CUDA (ROCm) tensor: the model runs in HIP kernels only")
         if x.dim() != 3 or x.shape[2] != self.N_BINS:
             raise ValueError(f"expected features [batch, frames, {self.N_BINS}], got {tuple(x.shape)}")
-        if x.shape[1] % 4:
-            raise ValueError(f"{x.shape[1]} frames: the HIP path needs a multiple of 4 (pooling (2,2),(2,2),(1,2))")
-        if alphas is None:
-            alphas = [float(torch.rand(1)) for _ in range(3)]       # models.py:91, block order
-        alphas = [float(a) for a in alphas]
-        if len(alphas) != 3:
-            raise ValueError("alphas: one ShakeShake mixing weight per block (3)")
-        return x.to(torch.float32).contiguous(), (C.c_float * 3)(*alphas)
+        return x.to(torch.float32).contiguous(), self.draw_alphas(alphas)
 
 
 class ShakeRCNN(_ShakeBase):
@@ -216,13 +247,21 @@ class ShakeRCNN(_ShakeBase):
         self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_shake_rcnn_destroy, handle)
         return handle
 
+    def _workspace_bytes(self, handle, B, T):
+        return _lib.lib().sedmi_shake_rcnn_workspace_bytes(handle, B, T)
+
+    def _forward_into(self, handle, x_ptr, B, T, out, ws, ws_bytes, stream, alphas=None):
+        _lib.check(_lib.lib().sedmi_shake_rcnn_forward_f32(handle, x_ptr, B, T, self.draw_alphas(alphas), _lib.ptr(out),
+                                                           _lib.ptr(ws), ws_bytes, stream),
+                   "sedmi_shake_rcnn_forward_f32")
+
     def forward(self, x, alphas=None):
         x, al = self._prepare(x, alphas)
         handle = self._get_handle(x.device)
         B, T, _ = x.shape
         lib = _lib.lib()
         logits = torch.empty((B, T // 4, self.num_classes), dtype=torch.float32, device=x.device)
-        if B == 0 or T == 0:
+        if B == 0 or T < 4:
             return logits
         ws_bytes = lib.sedmi_shake_rcnn_workspace_bytes(handle, B, T)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
@@ -239,7 +278,7 @@ class ShakeRCNN(_ShakeBase):
         B, T, _ = x.shape
         lib = _lib.lib()
         seq = torch.empty((B, T // 4, 6144), dtype=torch.float32, device=x.device)
-        if B == 0 or T == 0:
+        if B == 0 or T < 4:
             return seq
         ws_bytes = lib.sedmi_shake_rcnn_workspace_bytes(handle, B, T)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
@@ -299,13 +338,21 @@ class ShakeTransformer(_ShakeBase):
         self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_shake_transformer_destroy, handle)
         return handle
 
+    def _workspace_bytes(self, handle, B, T):
+        return _lib.lib().sedmi_shake_transformer_workspace_bytes(handle, B, T)
+
+    def _forward_into(self, handle, x_ptr, B, T, out, ws, ws_bytes, stream, alphas=None):
+        _lib.check(_lib.lib().sedmi_shake_transformer_forward_f32(handle, x_ptr, B, T, self.draw_alphas(alphas),
+                                                                  _lib.ptr(out), _lib.ptr(ws), ws_bytes, stream),
+                   "sedmi_shake_transformer_forward_f32")
+
     def forward(self, x, alphas=None):
         x, al = self._prepare(x, alphas)
         handle = self._get_handle(x.device)
         B, T, _ = x.shape
         lib = _lib.lib()
         logits = torch.empty((B, T // 4, self.num_classes), dtype=torch.float32, device=x.device)
-        if B == 0 or T == 0:
+        if B == 0 or T < 4:
             return logits
         ws_bytes = lib.sedmi_shake_transformer_workspace_bytes(handle, B, T)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)

@@ -4,8 +4,11 @@ by the reference (nnet/CNN.py:33-100) loads unchanged: ``cnn.conv{i}``,
 ``dropout{i}`` / ``pooling{i}`` entries the reference's Sequential also holds.
 
 These modules only own tensors.  The arithmetic of the stack runs in
-csrc/crnn.hip (conv0_kernel, conv_mfma_kernel) and is reached through
-``CRNN.forward``; calling a container directly is an error, not a CPU path.
+csrc/crnn.hip and csrc/conv_split.h (default: conv0_split_kernel and
+conv_split_kernel, float32 operands as f16 hi/lo halves on the f16 matrix
+cores; exact-float32 mode: conv0_kernel and conv_mfma_kernel) and is reached
+through ``CRNN.forward``; calling a container directly is an error, not a CPU
+path.
 """
 import torch.nn as nn
 

@@ -73,8 +73,9 @@ class CRNN(nn.Module):
         self._handle = None
         self._handle_sig = None
         self._handle_fin = None
-        # arithmetic of conv blocks 1..6: "split_f16" (default; float32 operands as two f16 halves on the
-        # f16 matrix cores, float32-grade accuracy) or "f32" (exact float32 MFMA, ~4x slower)
+        # arithmetic of the conv blocks, the GRU input projections and the recurrence: "split_f16" (default;
+        # float32 operands as two f16 halves on the f16 matrix cores, float32-grade accuracy; input features of
+        # any magnitude, activations between layers must stay below 65504) or "f32" (exact float32, ~3x slower)
         self.conv_precision = os.environ.get("SEDMI_CONV_PRECISION", "split_f16")
 
     # ------------------------------------------------------------------ handle
@@ -142,6 +143,22 @@ class CRNN(nn.Module):
         if self._handle_fin is not None:
             self._handle_fin()          # runs sedmi_crnn_destroy once
         self._handle = self._handle_sig = self._handle_fin = None
+
+    # ---- what pipeline.SedPipeline needs from a model: output kind, shapes, and a forward into given buffers
+    returns_logits = False              # CRNN.forward ends in a sigmoid (CRNN.py:143; training.py:358)
+    time_pooling = 2
+    feature_width = 128
+
+    @property
+    def n_outputs(self):
+        return int(self.nclass)
+
+    def _workspace_bytes(self, handle, B, T):
+        return _lib.lib().sedmi_crnn_workspace_bytes(handle, B, T)
+
+    def _forward_into(self, handle, x_ptr, B, T, out, ws, ws_bytes, stream, alphas=None):
+        _lib.check(_lib.lib().sedmi_crnn_forward_f32(handle, x_ptr, B, T, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                                     stream), "sedmi_crnn_forward_f32")
 
     # ----------------------------------------------------------------- forward
     def _prepare(self, x):

@@ -1,7 +1,8 @@
 """Parameter container for the recurrent part, named like the reference's
 ``BidirectionalGRU`` (nnet/RNN.py:7-30) so that ``rnn.rnn.weight_ih_l0`` ...
-load unchanged.  The recurrence itself runs in csrc/crnn.hip (linear_kernel +
-gru_kernel) through ``CRNN.forward``."""
+load unchanged.  The recurrence itself runs in the HIP kernels (default:
+linear_split_kernel in csrc/conv_split.h + gru_split_kernel in csrc/crnn.hip;
+exact-float32 mode: linear_kernel + gru_kernel) through ``CRNN.forward``."""
 import torch.nn as nn
 
 

@@ -5,9 +5,12 @@ per file chops the audio into ``clip_length`` ms pieces (feature_extraction.py:3
 zero-pads the last one (:41-42), runs mel extraction, the model and a D2H copy
 clip by clip (training.py:345-348), concatenates the frame predictions
 (:350) and decodes them with the file's duration (:353-358).  Here whole files
-are grouped into batches of clips that go through mel -> CRNN -> decode on the GPU
+are grouped into batches of clips that go through mel -> model -> decode on the GPU
 in one pass (``SedPipeline``); a file's clips are decoded as one frame sequence
 with the reference's cutoff ``int(duration / block) + 1`` (evaluation.py:58).
+``model`` is any of the four ``--model`` choices (training.py:200-217);
+``apply_sigmoid=None`` follows training.py:358 (False for the baseline CRNN, True
+for the models that return logits).
 """
 from __future__ import annotations
 
@@ -19,12 +22,16 @@ from .pipeline import SedPipeline
 
 
 def predict_files(model, test_files, dataset_location, dataset, clip_length, n_fft, n_mels, hop_length, win_length,
-                  id2cls, block_length, decision_threshold=0.5, apply_sigmoid=False, *, device=None,
-                  audio_loader=None, audio_duration=None, batch_clips=1024, median_window=1, return_probs=False):
+                  id2cls, block_length, decision_threshold=0.5, apply_sigmoid=None, *, device=None,
+                  audio_loader=None, audio_duration=None, batch_clips=1024, median_window=1, return_probs=False,
+                  alphas=None):
     """Events of every file as ``(file, onset_s, offset_s, label)`` tuples with
     float64 times, files in input order, class-major inside a file
     (evaluation.py:61-78).  With ``return_probs`` also {file: ndarray
-    [clips * frames, n_cls]} of the concatenated frame predictions."""
+    [clips * frames, n_cls]} of the concatenated frame predictions (what the model
+    returns: probabilities for the CRNN, logits otherwise).  ``alphas``: fixed
+    ShakeShake mixing weights for the Shake models (default: drawn per batch with
+    ``torch.rand(1)`` as the reference's eval mode does, models.py:88-91)."""
     sr = fe.sampling_rates[dataset]
     clip_s = 0.001 * clip_length
     n_clip = int(sr * clip_s)
@@ -44,7 +51,7 @@ def predict_files(model, test_files, dataset_location, dataset, clip_length, n_f
         y = torch.from_numpy(np.stack([c for _, _, clips in group for c in clips])).to(device)
         counts = [len(clips) for _, _, clips in group]
         cutoffs = [int(dur / block_s) + 1 for _, dur, _ in group]              # evaluation.py:58
-        out = pipe.run(y, clips_per_recording=counts, cutoffs=cutoffs)
+        out = pipe.run(y, clips_per_recording=counts, cutoffs=cutoffs, alphas=alphas)
         names = [f for f, _, _ in group]
         predictions.extend(pipe.events(out, id2cls, names))
         if return_probs:

@@ -49,6 +49,20 @@ def test_stages_match_reference_golden(golden_dir, fname, seed, ncls, precision)
     assert np.abs(full.cpu().numpy() - g["probs"]).max() < 1e-4     # well inside the 1e-3 budget
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("tag,seed,ncls", [("seed0", 0, 10), ("seed3_small", 3, 6), ("92cls", 5, 92), ("1cls", 6, 1)])
+def test_forward_matches_reference_crnn_forward(golden_dir, tag, seed, ncls, precision):
+    """Against outputs of the reference's CRNN.forward itself (nnet/CRNN.py:191-268), not only its
+    sub-modules: tests/golden/crnn_forward.npz."""
+    g = np.load(os.path.join(golden_dir, "crnn_forward.npz"))
+    feats = g[f"feats_{tag}"] if f"feats_{tag}" in g else np.load(os.path.join(golden_dir, f"crnn_{tag}.npz"))["feats"]
+    m, _ = _model(seed, ncls, precision)
+    got = m(torch.from_numpy(feats).cuda()).cpu().numpy()
+    want = g[f"probs_{tag}"]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-4          # well inside the 1e-3 budget
+
+
 def test_gru_stage_alone_matches_reference_golden(golden_dir):
     """Feeds the reference's own conv output to the HIP GRU, so that conv
     rounding cannot mask or cause a recurrence error."""

@@ -1,0 +1,99 @@
+"""SedPipeline bookkeeping (needs an MI355X): the model handle is looked up on every run, buffers are reused
+across batch sizes, and the two exchange steps run over RCCL (backend "nccl") on device tensors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn as ocrnn, mel as omel
+from sound_event_detection_amd import synth
+
+pytestmark = pytest.mark.gpu
+SR, N_FFT, HOP, WIN = 16000, 2048, 320, 640
+
+
+def _crnn(seed):
+    from sound_event_detection_amd.nnet import CRNN
+    m = CRNN(dropout=0.5, rnn_layers=2, n_in_channel=1, nclass=10, attention=True, n_RNN_cell=128, activation='glu',
+             rnn_type='BGRU', kernel_size=[3] * 7, padding=[1] * 7, stride=[1] * 7,
+             nb_filters=[16, 32, 64, 128, 128, 128, 128], pooling=[[2, 2]] + [[1, 2]] * 6, dropout_recurrent=0)
+    m.load_state_dict(synth.synth_crnn_state_dict(seed))
+    m.eval()
+    return m.cuda()
+
+
+def test_new_weights_and_interleaved_forward_reach_the_pipeline():
+    """run, load_state_dict with other weights, model(x) in between (which rebuilds the packed handle and frees
+    the old one), run again on the same shape: the second run must use the new weights."""
+    from sound_event_detection_amd.pipeline import SedPipeline
+    m = _crnn(0)
+    pipe = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN)
+    y = synth.synth_clips(7, 3)
+    yd = torch.from_numpy(y).cuda()
+    feats = np.stack([omel.clip_feature(c, SR, N_FFT, 128, HOP, WIN) for c in y])
+    a = pipe.run(yd)["probs"].clone()
+    want0 = ocrnn.crnn_forward(synth.synth_crnn_state_dict(0), torch.from_numpy(feats)).numpy()
+    assert np.abs(a.cpu().numpy() - want0).max() < 1e-3
+    sd1 = synth.synth_crnn_state_dict(9)
+    m.load_state_dict(sd1)
+    m(torch.rand(1, 64, 128, device="cuda"))
+    b = pipe.run(yd)["probs"].clone()
+    want1 = ocrnn.crnn_forward(sd1, torch.from_numpy(feats)).numpy()
+    assert np.abs(b.cpu().numpy() - want1).max() < 1e-3
+    assert np.abs(want1 - want0).max() > 1e-2
+    # the precision switch also takes effect on a cached shape
+    m.conv_precision = "f32"
+    c = pipe.run(yd)["probs"].clone()
+    assert np.abs(c.cpu().numpy() - want1).max() < 1e-3 and not torch.equal(b, c)
+
+
+def test_buffers_are_reused_for_smaller_batches_and_other_recording_tables():
+    from sound_event_detection_amd.pipeline import SedPipeline
+    m = _crnn(0)
+    pipe = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN)
+    yd = torch.from_numpy(synth.synth_clips(20, 6)).cuda()
+    id2cls = {i: f"c{i}" for i in range(10)}
+    out = pipe.run(yd, clips_per_recording=[2, 4], cutoffs=[400, 1001])
+    full = out["probs"].clone()
+    ev_full = pipe.events(out, id2cls, ["a", "b"])
+    buf = pipe._buf
+    ptrs = (buf["mel"].data_ptr(), buf["out"].data_ptr(), buf["ev"].data_ptr())
+    out2 = pipe.run(yd[:2].contiguous(), clips_per_recording=[2], cutoffs=[400])
+    assert pipe._buf is buf and ptrs == (buf["mel"].data_ptr(), buf["out"].data_ptr(), buf["ev"].data_ptr())
+    assert torch.equal(out2["probs"], full[:2])
+    ev_a = pipe.events(out2, id2cls, ["a"])
+    assert ev_a == [e for e in ev_full if e[0] == "a"] and len(ev_a) > 0
+    with pytest.raises(ValueError):
+        pipe.run(yd, clips_per_recording=[2, 3])
+
+
+def test_exchange_steps_over_rccl_on_device_tensors():
+    """backend "nccl" is RCCL on ROCm.  One rank on the one GPU of the test box: initialises the communicator and
+    runs both collectives of parallel.py on device tensors."""
+    import torch.distributed as dist
+    from sound_event_detection_amd import feature_extraction as fe, parallel
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        local = torch.rand(5, 250, 10, device=dev)
+        got = parallel.all_gather_probs(local, 5)
+        assert got.is_cuda and torch.equal(got, local)
+        mel = fe.melspectrogram(torch.from_numpy(synth.synth_clips(0, 2)).to(dev), SR, N_FFT, 128, HOP, WIN)
+        s, s2, cnt = fe.mel_statistics(mel)
+        mean, std = parallel.all_reduce_mel_stats(s, s2, cnt)
+        ref = mel.double().permute(1, 0, 2).reshape(128, -1)
+        assert torch.allclose(mean, ref.mean(1), rtol=1e-9) and torch.allclose(std, ref.std(1, unbiased=False), rtol=1e-6)
+        # the asynchronous form bench.py uses for N > 1: the collective runs on RCCL's stream beside the compute
+        out = torch.empty((1,) + tuple(local.shape), device=dev)
+        work = dist.all_gather_into_tensor(out, local, async_op=True)
+        work.wait()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out[0], local)
+    finally:
+        dist.destroy_process_group()
