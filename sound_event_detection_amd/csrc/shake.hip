@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 
 namespace {
@@ -696,13 +697,222 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The whole H = 1024 recurrence in ONE launch (small batches, long sequences: minutes-long recordings).
+//
+// grid (64 unit groups, 2 directions, n_sets clip sets), 512 threads, one workgroup per CU.  A workgroup owns 16
+// hidden units x 3 gates of one direction over the whole K = 1024 and keeps that slice of W_hh in registers for the
+// lifetime of the kernel as f16 (hi, lo) B fragments: wave w holds K slice [128 w, 128 w + 128) (96 VGPRs).  Clips
+// come in groups of 16 (= the M of v_mfma_f32_16x16x32_f16); a workgroup serves the groups of its clip set one
+// after the other inside every step, so that one group's exchange latency passes while the next group computes.
+//
+// Per step and group: every workgroup of the direction needs ALL of h_{t-1} (16 clips x 1024) and produces 16
+// units of h_t.  h travels between workgroups through a double-buffered exchange array in device memory, already
+// split into f16 hi / lo planes and laid out [producer workgroup][clip][unit] so that a consumer lane reads its
+// MFMA A fragment (8 consecutive k of one clip) straight into registers with one 16-byte load: no LDS staging and
+// no workgroup barrier in front of the matrix product.  The hand-off is flag based, independent of dispatch
+// order, timing and XCD placement:
+//   producer: wave 7 alone stores the workgroup's 1 KB (16-byte write-through sc1 stores), drains them
+//             (s_waitcnt vmcnt(0)), then its lane 0 stores flag = step + 1 (sc1);
+//   consumer: each wave polls the 8 flags of the 8 producers of ITS K slice (relaxed sc1 loads, s_sleep between
+//             polls), and only after its own poll has matched issues its sc1 payload loads.
+// Buffer parity: step s writes buffer s & 1 and reads (s - 1) & 1; a workgroup can only write buffer s & 1 at step s
+// after every flag has reached s, i.e. after every reader of step s - 1 (which read that buffer) has published.
+// The K slices are reduced across the eight waves through LDS; threads 0..255 then do the gate arithmetic for
+// one (clip, unit) each, keep their h in a register for the next step, write the output row and stage the f16
+// halves for wave 7.  gi of the next step is requested a step ahead (after the A fragment loads, so that its HBM
+// latency is never in front of them in the in-order return queue).
+// Every spin is bounded: a wave that gives up raises *status and stops waiting, so the grid always drains; the
+// head kernel that follows turns a raised status into NaN logits.
+// ---------------------------------------------------------------------------
+constexpr int GP_U = 16;                       // hidden units per workgroup
+constexpr int GP_WG = GB_H / GP_U;             // 64 workgroups per direction and clip set
+constexpr int GP_CLIPS = 16;                   // clips per group
+constexpr int GP_MAX_G = 4;                    // groups per workgroup
+constexpr unsigned GP_SPIN_LIMIT = 3000000u;   // ~ seconds
+constexpr int GP_RED_BYTES = 8 * 3 * 256 * 4;      // followed by the 1 KB f16 staging planes
+constexpr int GP_LDS_BYTES = 96 * 1024;        // more than half of a CU's LDS: never two workgroups on one CU
+constexpr int GP_STATUS_WORDS = 64;            // status word + padding in front of the flags
+
+using gu32 = __attribute__((address_space(1))) unsigned;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+using f32x4g = __attribute__((ext_vector_type(4))) float;
+
+__host__ __device__ constexpr long gp_hx_index(int par, int dir, int n_groups, int gg, int plane, int wg) {
+    return ((((static_cast<long>(par) * 2 + dir) * n_groups + gg) * 2 + plane) * GP_WG + wg) * 32;   // uint4 units
+}
+
+template <int G>
+__global__ __launch_bounds__(512) void gru_big_persistent_kernel(
+    const float *__restrict__ gi,       // [clip][T][2][3][1024]: W_ih x + b_ih (+ b_hh for r, z)
+    const uint4 *__restrict__ whh,      // packed split [2][1024/16][2][3072][16], columns [unit group of 32][gate][32]
+    float whh_oscale, const float *__restrict__ bhn,   // [2][1024]
+    float *__restrict__ out,            // [clip][T][2048]
+    uint4 *hx,                          // exchange: [2 parity][2 dir][n_groups][2 planes][64 wg][16 clips][16 units] f16
+    unsigned *sync_words,               // [GP_STATUS_WORDS] status, then flags [2 dir][n_groups][64]; zeroed before the launch
+    long n_clips, int T, int n_groups, int n_sets) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *red = reinterpret_cast<float *>(smem);                       // [wave][gate][clip][unit]
+    char *stage = smem + GP_RED_BYTES;                                  // [plane][clip][unit] f16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int wg = blockIdx.x, dir = blockIdx.y, set = blockIdx.z;
+    gu32 *status = (gu32 *)sync_words;
+    gu32 *flags = (gu32 *)(sync_words + GP_STATUS_WORDS) + static_cast<long>(dir) * n_groups * GP_WG;
+
+    // this wave's slice of W_hh: B fragment of k-step 4 wave + s, column = unit 16 wg + n16 of gate q
+    f16x8 wh[3][4], wl[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int ks16 = 2 * (4 * wave + s4) + (kg >> 1);
+            const int col = (wg >> 1) * 96 + q * 32 + (wg & 1) * 16 + n16;
+            const uint4 *p = whh + ((static_cast<long>(dir) * (GB_H / 16) + ks16) * 2 * (3 * GB_H) + col) * 2 + (kg & 1);
+            wh[q][s4] = __builtin_bit_cast(f16x8, p[0]);
+            wl[q][s4] = __builtin_bit_cast(f16x8, p[2 * 3 * GB_H]);
+        }
+
+    // gate role of threads 0..255: (clip c of the group, unit n of the workgroup)
+    const bool gate_thread = tid < 256;
+    const int gc = (tid >> 4) & 15, gn = tid & 15, j = wg * GP_U + gn;
+    const float b_hn = bhn[dir * GB_H + j];
+    float hprev[G], gcur[G][3], gnext[G][3];
+    const float *gip[G];
+    float *outp[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int gg = set + n_sets * g;
+        const long b = static_cast<long>(gg) * GP_CLIPS + gc;
+        live[g] = gate_thread && gg < n_groups && b < n_clips;
+        const long bc = live[g] ? b : 0;
+        gip[g] = gi + (bc * T * 2 + dir) * (3L * GB_H) + j;
+        outp[g] = out + bc * T * (2L * GB_H) + dir * GB_H + j;
+        hprev[g] = 0.f;
+        const long t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gnext[g][q] = live[g] ? gip[g][t0 * (6L * GB_H) + q * GB_H] : 0.f;
+            gcur[g][q] = 0.f;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        hx, 0, static_cast<int>(gp_hx_index(2, 0, n_groups, 0, 0, 0) * 16), 0x00020000);
+    bool gave_up = false;
+
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        const long t = dir ? T - 1 - s : s, tn = dir ? T - 2 - s : s + 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = set + n_sets * g;
+            if (gg >= n_groups) continue;                     // uniform over the workgroup
+            // this step's gate inputs were requested a step ago (behind that step's A fragments); taking them over
+            // here, in front of the poll, is where waiting for them costs nothing
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gcur[g][q] = gnext[g][q];
+            f32x4g acc[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+            if (s > 0) {
+                // wait for the 8 producers of this wave's K slice
+                gu32 *fp = flags + static_cast<long>(gg) * GP_WG + 8 * wave + (lane & 7);
+                if (!gave_up) {
+                    unsigned spins = 0;
+                    while (true) {
+                        const unsigned f = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(f >= static_cast<unsigned>(s))) break;
+                        if (++spins > GP_SPIN_LIMIT) {
+                            gave_up = true;
+                            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the loads below the poll
+                // A fragments of h_{t-1}: row = clip n16, k = 128 wave + 32 s4 + 8 kg .. + 7 -> producer 8 wave + 2 s4 + kg / 2
+                f16x8 ah[4], al[4];
+                const int par = (s - 1) & 1;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int wgp = 8 * wave + 2 * s4 + (kg >> 1);
+                    const int o_h = static_cast<int>((gp_hx_index(par, dir, n_groups, gg, 0, wgp) + n16 * 2 + (kg & 1)) * 16);
+                    const int o_l = static_cast<int>((gp_hx_index(par, dir, n_groups, gg, 1, wgp) + n16 * 2 + (kg & 1)) * 16);
+                    ah[s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_h, 0, 16));
+                    al[s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_l, 0, 16));
+                }
+                // all eight requests go out before the first product: left alone, the scheduler reuses one
+                // register quad for every fragment and pays eight round trips one after the other
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s4], wh[q][s4], acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s4], wl[q][s4], acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s4], wh[q][s4], acc[q], 0, 0, 0);
+                }
+            }
+            // the next step's gate inputs, requested behind the A fragments
+            if (live[g] && s + 1 < T) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gnext[g][q] = gip[g][tn * (6L * GB_H) + q * GB_H];
+            }
+            // partial sums of this wave's K slice: accumulator register i = clip 4 kg + i, unit n16
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[((wave * 3 + q) * 16 + 4 * kg + i) * 16 + n16] = acc[q][i];
+            __syncthreads();
+            if (gate_thread) {
+                float gh[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) sum += red[(w * 3 + q) * 256 + tid];
+                    gh[q] = sum * whh_oscale;
+                }
+                const float rg = sigmoidf_fast(gcur[g][0] + gh[0]);
+                const float zg = sigmoidf_fast(gcur[g][1] + gh[1]);
+                const float ng = tanhf_fast(fmaf(rg, gh[2] + b_hn, gcur[g][2]));
+                const float hv = fmaf(zg, hprev[g] - ng, ng);             // (1 - z) * n + z * h
+                hprev[g] = hv;
+                if (live[g]) outp[g][t * (2L * GB_H)] = hv;
+                _Float16 hi, lo;
+                split_f16(hv, hi, lo);
+                *reinterpret_cast<_Float16 *>(stage + tid * 2) = hi;
+                *reinterpret_cast<_Float16 *>(stage + 512 + tid * 2) = lo;
+            }
+            __syncthreads();
+            if (wave == 7 && s + 1 < T) {
+                // publish: 64 lanes x 16 bytes = both planes of this workgroup's [16 clips][16 units]
+                const int plane = lane >> 5, idx = lane & 31;
+                const uint4 v = *reinterpret_cast<const uint4 *>(stage + plane * 512 + idx * 16);
+                const int o = static_cast<int>((gp_hx_index(s & 1, dir, n_groups, gg, plane, wg) + idx) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), hrs, o, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(flags + static_cast<long>(gg) * GP_WG + wg, static_cast<unsigned>(s + 1), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // [LayerNorm(D) -> LeakyReLU(0.01) ->] Linear(D, n_cls): one wave per row
 // ---------------------------------------------------------------------------
 template <int D, bool DO_LN>
 __global__ __launch_bounds__(256) void ln_head_kernel(const float *__restrict__ x, const float *__restrict__ lw,
                                                       const float *__restrict__ lb, const float *__restrict__ fw,
                                                       const float *__restrict__ fb, float *__restrict__ out,
-                                                      long n_rows, int n_cls) {
+                                                      long n_rows, int n_cls, const unsigned *status) {
+    // status: word raised by a kernel upstream that could not finish its work (nullptr: none); the logits are
+    // then NaN rather than plausible numbers
+    const bool upstream_failed = status != nullptr && *status != 0u;
     constexpr int PER = D / 64;
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -741,7 +951,7 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const float *__restrict__ 
         for (int i = 0; i < PER; ++i) a = fmaf(v[i], wr[lane + 64 * i], a);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) out[row * n_cls + c] = a + fb[c];
+        if (lane == 0) out[row * n_cls + c] = upstream_failed ? __builtin_nanf("") : a + fb[c];
     }
 }
 
@@ -1104,7 +1314,7 @@ struct EncoderLayerDev {
 }  // namespace
 
 struct sedmi_shake_rcnn {
-    int n_class = 0;
+    int n_class = 0, num_cus = 0;
     ShakeCnnDev cnn;
     LinearDev wih;                       // both directions: N = 2 * 3072
     uint16_t *d_whh = nullptr;
@@ -1134,6 +1344,9 @@ namespace {
 struct ShakeScratch {
     float *u1, *y1, *u2, *y2, *u3, *seq;
     float *gi, *rec, *h0, *h1;               // ShakeRCNN
+    uint4 *hx;                               // persistent recurrence: exchange buffers
+    unsigned *sync_words;                    // and its status word + flags
+    size_t sync_bytes;
     float *x, *qkv, *att, *ff;               // ShakeTransformer
     size_t bytes;
 };
@@ -1160,6 +1373,10 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
         sc.rec = take(static_cast<size_t>(n) * T4 * 2048);
         sc.h0 = take(static_cast<size_t>(2) * n * GB_H);
         sc.h1 = take(static_cast<size_t>(2) * n * GB_H);
+        const long n_groups = std::min<long>(sedmi::ceil_div(n, GP_CLIPS), 2 * GP_MAX_G);
+        sc.hx = reinterpret_cast<uint4 *>(take(static_cast<size_t>(gp_hx_index(2, 0, static_cast<int>(n_groups), 0, 0, 0)) * 4));
+        sc.sync_bytes = sizeof(unsigned) * (GP_STATUS_WORDS + 2 * n_groups * GP_WG);
+        sc.sync_words = reinterpret_cast<unsigned *>(take(sc.sync_bytes / sizeof(float)));
     } else if (kind == SHAKE_TRANSFORMER) {
         sc.x = take(static_cast<size_t>(n) * T4 * 1024);
         sc.qkv = take(static_cast<size_t>(n) * T4 * 3072);
@@ -1247,10 +1464,46 @@ int launch_linear(const char *name, const LinearDev &L, const float *A, float *C
     return SEDMI_OK;
 }
 
+// 0: one launch per step; 1: the persistent kernel whenever the batch fits it (default); read per call so
+// that a benchmark can compare the two
+bool gru_persistent_wanted() {
+    const char *e = std::getenv("SEDMI_SHAKE_GRU_PERSISTENT");
+    return e == nullptr || e[0] != '0';
+}
+
+template <int G>
+int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_groups, int n_sets, const ShakeScratch &sc,
+                          hipStream_t s) {
+    auto kern = gru_big_persistent_kernel<G>;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        GP_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
+                       reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words, n,
+                       T4, n_groups, n_sets);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+// sets *used_persistent; the status word at sc.sync_words[0] is zeroed either way (the head kernel reads it)
 int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
     const long rows = n * T4;
     int rc;
     if ((rc = launch_linear("shake_gru_input_proj", m->wih, seq, sc.gi, rows, false, s))) return rc;
+    SEDMI_CHECK_HIP(hipMemsetAsync(sc.sync_words, 0, sc.sync_bytes, s));
+    // Small batches (minutes-long recordings: few clips, thousands of steps): the whole recurrence in one launch,
+    // W_hh resident in registers across 128 or 256 CUs.  Needs every workgroup resident at once (one per CU).
+    const int n_groups = static_cast<int>(sedmi::ceil_div(n, GP_CLIPS));
+    const int n_sets = n_groups >= 2 && 2 * 2 * GP_WG <= m->num_cus ? 2 : 1;
+    const int G = static_cast<int>(sedmi::ceil_div(n_groups, n_sets));
+    if (gru_persistent_wanted() && G <= GP_MAX_G && 2 * GP_WG * n_sets <= m->num_cus && T4 >= 2) {
+        sedmi::ProfileScope prof("shake_gru_persistent", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
+        switch (G) {
+            case 1: return launch_gru_persistent<1>(m, n, T4, n_groups, n_sets, sc, s);
+            case 2: return launch_gru_persistent<2>(m, n, T4, n_groups, n_sets, sc, s);
+            case 3: return launch_gru_persistent<3>(m, n, T4, n_groups, n_sets, sc, s);
+            default: return launch_gru_persistent<4>(m, n, T4, n_groups, n_sets, sc, s);
+        }
+    }
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));
     const size_t lds = 4 * 2 * 32 * ((GB_H / 4) * 2 + 16);
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_big_step_kernel),
@@ -1455,6 +1708,12 @@ int sedmi_shake_rcnn_create(sedmi_shake_rcnn **out, const sedmi_shake_rcnn_weigh
 
     auto *m = new sedmi_shake_rcnn();
     m->n_class = w->n_class;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&m->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            m->num_cus = 0;             // unknown: the persistent recurrence is not used
+    }
     auto fail = [&](int code) { sedmi_shake_rcnn_destroy(m); return code; };
     if ((rc = create_shake_cnn(m->cnn, w->cnn))) return fail(rc);
     {
@@ -1536,7 +1795,7 @@ int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *m, const float *feats, 
     const long rows = n * T4;
     sedmi::ProfileScope prof("shake_ln_head", s, 2.0 * rows * 2048.0 * m->n_class, 4.0 * rows * (2048.0 + m->n_class));
     hipLaunchKernelGGL((ln_head_kernel<2048, true>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
-                       sc.rec, m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class);
+                       sc.rec, m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class, sc.sync_words);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
@@ -1614,7 +1873,7 @@ int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const 
     const long rows = n * T4;
     sedmi::ProfileScope prof("shake_tf_head", s, 2.0 * rows * 1024.0 * m->n_class, 4.0 * rows * (1024.0 + m->n_class));
     hipLaunchKernelGGL((ln_head_kernel<1024, false>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
-                       sc.x, nullptr, nullptr, m->d_fw, m->d_fb, logits, rows, m->n_class);
+                       sc.x, nullptr, nullptr, m->d_fw, m->d_fb, logits, rows, m->n_class, nullptr);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

@@ -130,3 +130,26 @@ def test_crnn_predict_files_60s_clips_n_fft_4096(tmp_path):
     assert len(preds) == len(want_events) and len(preds) > 50
     for g, w in zip(preds, want_events):
         assert g[0] == w[0] and g[3] == w[3] and g[1] == w[1] and g[2] == w[2]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_clips,frames", [(1, 40), (16, 24), (17, 16), (64, 16), (128, 12), (130, 8)])
+def test_shake_rcnn_recurrence_in_one_launch_agrees_with_per_step_launches(n_clips, frames, monkeypatch):
+    """The H = 1024 recurrence runs as one persistent launch for up to 128 clips (groups of 16 clips, one or two
+    clip sets, workgroups exchanging h through device memory every step) and as one launch per step beyond; both
+    must give the oracle's logits.  SEDMI_SHAKE_GRU_PERSISTENT=0 selects the per-step kernel."""
+    from oracle import shake
+    m, sd = _shake("rcnn")
+    x = torch.from_numpy(synth.synth_shake_feats(60 + n_clips, n_clips, frames))
+    al = [0.45, 0.25, 0.65]
+    want = shake.shake_rcnn_forward(sd, x, al).numpy()
+    monkeypatch.setenv("SEDMI_SHAKE_GRU_PERSISTENT", "1")
+    one = m(x.cuda(), al).cpu().numpy()
+    again = m(x.cuda(), al).cpu().numpy()
+    monkeypatch.setenv("SEDMI_SHAKE_GRU_PERSISTENT", "0")
+    per_step = m(x.cuda(), al).cpu().numpy()
+    assert np.isfinite(one).all()
+    assert np.array_equal(one, again)                   # deterministic: no atomics, fixed reduction order
+    np.testing.assert_allclose(one, want, rtol=0, atol=ATOL_LOGITS)
+    np.testing.assert_allclose(per_step, want, rtol=0, atol=ATOL_LOGITS)
+    np.testing.assert_allclose(one, per_step, rtol=0, atol=2e-4)
