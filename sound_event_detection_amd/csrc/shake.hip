@@ -726,10 +726,9 @@ __global__ __launch_bounds__(256) void gru_big_step_kernel(
 // ---------------------------------------------------------------------------
 constexpr int GP_U = 16;                       // hidden units per workgroup
 constexpr int GP_WG = GB_H / GP_U;             // 64 workgroups per direction and clip set
-constexpr int GP_CLIPS = 16;                   // clips per group
-constexpr int GP_MAX_G = 4;                    // groups per workgroup
+constexpr int GP_MAX_G = 3;                    // groups per workgroup (four 32-clip groups would spill registers)
+constexpr int GP_MAX_MT = 2;                   // 16-clip MFMA tiles per group
 constexpr unsigned GP_SPIN_LIMIT = 3000000u;   // ~ seconds
-constexpr int GP_RED_BYTES = 8 * 3 * 256 * 4;      // followed by the 1 KB f16 staging planes
 constexpr int GP_LDS_BYTES = 96 * 1024;        // more than half of a CU's LDS: never two workgroups on one CU
 constexpr int GP_STATUS_WORDS = 64;            // status word + padding in front of the flags
 
@@ -737,22 +736,25 @@ using gu32 = __attribute__((address_space(1))) unsigned;
 using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
 using f32x4g = __attribute__((ext_vector_type(4))) float;
 
-__host__ __device__ constexpr long gp_hx_index(int par, int dir, int n_groups, int gg, int plane, int wg) {
-    return ((((static_cast<long>(par) * 2 + dir) * n_groups + gg) * 2 + plane) * GP_WG + wg) * 32;   // uint4 units
+// exchange array, in uint4 (16-byte) units: [parity][dir][group][plane][producer workgroup][16 mt clips][16 units] f16
+__host__ __device__ constexpr long gp_hx_index(int mt_tiles, int par, int dir, int n_groups, int gg, int plane, int wg) {
+    return ((((static_cast<long>(par) * 2 + dir) * n_groups + gg) * 2 + plane) * GP_WG + wg) * (32 * mt_tiles);
 }
 
-template <int G>
+// G: groups a workgroup serves per step; MT: 16-clip tiles per group (a group = 16 MT clips)
+template <int G, int MT>
 __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
     const float *__restrict__ gi,       // [clip][T][2][3][1024]: W_ih x + b_ih (+ b_hh for r, z)
     const uint4 *__restrict__ whh,      // packed split [2][1024/16][2][3072][16], columns [unit group of 32][gate][32]
     float whh_oscale, const float *__restrict__ bhn,   // [2][1024]
     float *__restrict__ out,            // [clip][T][2048]
-    uint4 *hx,                          // exchange: [2 parity][2 dir][n_groups][2 planes][64 wg][16 clips][16 units] f16
+    uint4 *hx,                          // exchange array (gp_hx_index)
     unsigned *sync_words,               // [GP_STATUS_WORDS] status, then flags [2 dir][n_groups][64]; zeroed before the launch
     long n_clips, int T, int n_groups, int n_sets) {
+    constexpr int CLIPS = 16 * MT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *red = reinterpret_cast<float *>(smem);                       // [wave][gate][clip][unit]
-    char *stage = smem + GP_RED_BYTES;                                  // [plane][clip][unit] f16
+    float *red = reinterpret_cast<float *>(smem);                       // [wave][gate][mt][clip 16][unit 16]
+    char *stage = smem + 8 * 3 * MT * 256 * 4;                          // [plane][clip 16 MT][unit 16] f16
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;
     const int wg = blockIdx.x, dir = blockIdx.y, set = blockIdx.z;
@@ -772,32 +774,31 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
             wl[q][s4] = __builtin_bit_cast(f16x8, p[2 * 3 * GB_H]);
         }
 
-    // gate role of threads 0..255: (clip c of the group, unit n of the workgroup)
+    // gate role of threads 0..255: unit n of the workgroup, clips c + 16 mt of the group
     const bool gate_thread = tid < 256;
     const int gc = (tid >> 4) & 15, gn = tid & 15, j = wg * GP_U + gn;
     const float b_hn = bhn[dir * GB_H + j];
-    float hprev[G], gcur[G][3], gnext[G][3];
-    const float *gip[G];
-    float *outp[G];
-    bool live[G];
+    float hprev[G][MT], gcur[G][MT][3], gnext[G][MT][3];
+    int clip_of[G][MT];                  // -1: no such clip (addresses are formed per use: pointers kept per
+    bool live[G][MT];                    // (group, tile) would cost 8 registers each)
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int gg = set + n_sets * g;
-        const long b = static_cast<long>(gg) * GP_CLIPS + gc;
-        live[g] = gate_thread && gg < n_groups && b < n_clips;
-        const long bc = live[g] ? b : 0;
-        gip[g] = gi + (bc * T * 2 + dir) * (3L * GB_H) + j;
-        outp[g] = out + bc * T * (2L * GB_H) + dir * GB_H + j;
-        hprev[g] = 0.f;
-        const long t0 = dir ? T - 1 : 0;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            gnext[g][q] = live[g] ? gip[g][t0 * (6L * GB_H) + q * GB_H] : 0.f;
-            gcur[g][q] = 0.f;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int gg = set + n_sets * g;
+            const long b = static_cast<long>(gg) * CLIPS + 16 * mt + gc;
+            live[g][mt] = gate_thread && gg < n_groups && b < n_clips;
+            clip_of[g][mt] = live[g][mt] ? static_cast<int>(b) : -1;
+            hprev[g][mt] = 0.f;
+            const long t0 = dir ? T - 1 : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                gnext[g][mt][q] = live[g][mt] ? gi[((b * T + t0) * 2 + dir) * (3L * GB_H) + q * GB_H + j] : 0.f;
+                gcur[g][mt][q] = 0.f;
+            }
         }
-    }
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
-        hx, 0, static_cast<int>(gp_hx_index(2, 0, n_groups, 0, 0, 0) * 16), 0x00020000);
+        hx, 0, static_cast<int>(gp_hx_index(MT, 2, 0, n_groups, 0, 0, 0) * 16), 0x00020000);
     bool gave_up = false;
 
 #pragma unroll 1
@@ -810,10 +811,14 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
             // this step's gate inputs were requested a step ago (behind that step's A fragments); taking them over
             // here, in front of the poll, is where waiting for them costs nothing
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gcur[g][q] = gnext[g][q];
-            f32x4g acc[3];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 3; ++q) gcur[g][mt][q] = gnext[g][mt][q];
+            f32x4g acc[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[mt][q] = f32x4g{0.f, 0.f, 0.f, 0.f};
             if (s > 0) {
                 // wait for the 8 producers of this wave's K slice
                 gu32 *fp = flags + static_cast<long>(gg) * GP_WG + 8 * wave + (lane & 7);
@@ -831,68 +836,89 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the loads below the poll
-                // A fragments of h_{t-1}: row = clip n16, k = 128 wave + 32 s4 + 8 kg .. + 7 -> producer 8 wave + 2 s4 + kg / 2
-                f16x8 ah[4], al[4];
+                // A fragments of h_{t-1}: row = clip 16 mt + n16, k = 128 wave + 32 s4 + 8 kg .. + 7 -> producer
+                // workgroup 8 wave + 2 s4 + kg / 2, its units 8 (kg & 1) .. + 7
+                f16x8 ah[MT][4], al[MT][4];
                 const int par = (s - 1) & 1;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int wgp = 8 * wave + 2 * s4 + (kg >> 1);
-                    const int o_h = static_cast<int>((gp_hx_index(par, dir, n_groups, gg, 0, wgp) + n16 * 2 + (kg & 1)) * 16);
-                    const int o_l = static_cast<int>((gp_hx_index(par, dir, n_groups, gg, 1, wgp) + n16 * 2 + (kg & 1)) * 16);
-                    ah[s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_h, 0, 16));
-                    al[s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_l, 0, 16));
-                }
-                // all eight requests go out before the first product: left alone, the scheduler reuses one
-                // register quad for every fragment and pays eight round trips one after the other
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int wgp = 8 * wave + 2 * s4 + (kg >> 1);
+                        const int in_block = (16 * mt + n16) * 2 + (kg & 1);
+                        const int o_h = static_cast<int>((gp_hx_index(MT, par, dir, n_groups, gg, 0, wgp) + in_block) * 16);
+                        const int o_l = static_cast<int>((gp_hx_index(MT, par, dir, n_groups, gg, 1, wgp) + in_block) * 16);
+                        ah[mt][s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_h, 0, 16));
+                        al[mt][s4] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, o_l, 0, 16));
+                    }
+                // all requests go out before the first product: left alone, the scheduler reuses one register
+                // quad for every fragment and pays the round trips one after the other
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s4], wh[q][s4], acc[q], 0, 0, 0);
+                    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s4], wl[q][s4], acc[q], 0, 0, 0);
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][s4], wh[q][s4], acc[mt][q], 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s4], wh[q][s4], acc[q], 0, 0, 0);
-                }
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][s4], wl[q][s4], acc[mt][q], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][s4], wh[q][s4], acc[mt][q], 0, 0, 0);
+                    }
             }
             // the next step's gate inputs, requested behind the A fragments
-            if (live[g] && s + 1 < T) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gnext[g][q] = gip[g][tn * (6L * GB_H) + q * GB_H];
-            }
-            // partial sums of this wave's K slice: accumulator register i = clip 4 kg + i, unit n16
+            for (int mt = 0; mt < MT; ++mt)
+                if (live[g][mt] && s + 1 < T) {
+                    const float *gp = gi + ((static_cast<long>(clip_of[g][mt]) * T + tn) * 2 + dir) * (3L * GB_H) + j;
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+                    for (int q = 0; q < 3; ++q) gnext[g][mt][q] = gp[q * GB_H];
+                }
+            // partial sums of this wave's K slice: accumulator register i = clip 16 mt + 4 kg + i, unit n16
 #pragma unroll
-                for (int i = 0; i < 4; ++i) red[((wave * 3 + q) * 16 + 4 * kg + i) * 16 + n16] = acc[q][i];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        red[(((wave * 3 + q) * MT + mt) * 16 + 4 * kg + i) * 16 + n16] = acc[mt][q][i];
             __syncthreads();
             if (gate_thread) {
-                float gh[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    float sum = 0.f;
+                for (int mt = 0; mt < MT; ++mt) {
+                    float gh[3];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) sum += red[(w * 3 + q) * 256 + tid];
-                    gh[q] = sum * whh_oscale;
+                    for (int q = 0; q < 3; ++q) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) sum += red[((w * 3 + q) * MT + mt) * 256 + tid];
+                        gh[q] = sum * whh_oscale;
+                    }
+                    const float rg = sigmoidf_fast(gcur[g][mt][0] + gh[0]);
+                    const float zg = sigmoidf_fast(gcur[g][mt][1] + gh[1]);
+                    const float ng = tanhf_fast(fmaf(rg, gh[2] + b_hn, gcur[g][mt][2]));
+                    const float hv = fmaf(zg, hprev[g][mt] - ng, ng);             // (1 - z) * n + z * h
+                    hprev[g][mt] = hv;
+                    if (live[g][mt]) out[(static_cast<long>(clip_of[g][mt]) * T + t) * (2L * GB_H) + dir * GB_H + j] = hv;
+                    _Float16 hi, lo;
+                    split_f16(hv, hi, lo);
+                    *reinterpret_cast<_Float16 *>(stage + (mt * 256 + tid) * 2) = hi;
+                    *reinterpret_cast<_Float16 *>(stage + (MT * 256 + mt * 256 + tid) * 2) = lo;
                 }
-                const float rg = sigmoidf_fast(gcur[g][0] + gh[0]);
-                const float zg = sigmoidf_fast(gcur[g][1] + gh[1]);
-                const float ng = tanhf_fast(fmaf(rg, gh[2] + b_hn, gcur[g][2]));
-                const float hv = fmaf(zg, hprev[g] - ng, ng);             // (1 - z) * n + z * h
-                hprev[g] = hv;
-                if (live[g]) outp[g][t * (2L * GB_H)] = hv;
-                _Float16 hi, lo;
-                split_f16(hv, hi, lo);
-                *reinterpret_cast<_Float16 *>(stage + tid * 2) = hi;
-                *reinterpret_cast<_Float16 *>(stage + 512 + tid * 2) = lo;
             }
             __syncthreads();
             if (wave == 7 && s + 1 < T) {
-                // publish: 64 lanes x 16 bytes = both planes of this workgroup's [16 clips][16 units]
-                const int plane = lane >> 5, idx = lane & 31;
-                const uint4 v = *reinterpret_cast<const uint4 *>(stage + plane * 512 + idx * 16);
-                const int o = static_cast<int>((gp_hx_index(s & 1, dir, n_groups, gg, plane, wg) + idx) * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), hrs, o, 0, 16);
+                // publish: both planes of this workgroup's [16 MT clips][16 units], 16 bytes per lane and store
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const int u = lane + 64 * r, plane = u / (32 * MT), idx = u % (32 * MT);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + u * 16);
+                    const int o = static_cast<int>((gp_hx_index(MT, s & 1, dir, n_groups, gg, plane, wg) + idx) * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), hrs, o, 0, 16);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0)
                     __hip_atomic_store(flags + static_cast<long>(gg) * GP_WG + wg, static_cast<unsigned>(s + 1), __ATOMIC_RELAXED,
@@ -1373,8 +1399,10 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
         sc.rec = take(static_cast<size_t>(n) * T4 * 2048);
         sc.h0 = take(static_cast<size_t>(2) * n * GB_H);
         sc.h1 = take(static_cast<size_t>(2) * n * GB_H);
-        const long n_groups = std::min<long>(sedmi::ceil_div(n, GP_CLIPS), 2 * GP_MAX_G);
-        sc.hx = reinterpret_cast<uint4 *>(take(static_cast<size_t>(gp_hx_index(2, 0, static_cast<int>(n_groups), 0, 0, 0)) * 4));
+        // sized for the largest geometry the persistent recurrence takes (2 sets x GP_MAX_G groups of 16 GP_MAX_MT clips)
+        // (in units of 16 clips; a batch in 32-clip groups rounds up to whole groups)
+        const long n_groups = std::min<long>(GP_MAX_MT * sedmi::ceil_div(n, 16 * GP_MAX_MT), 2 * GP_MAX_G * GP_MAX_MT);
+        sc.hx = reinterpret_cast<uint4 *>(take(static_cast<size_t>(gp_hx_index(1, 2, 0, static_cast<int>(n_groups), 0, 0, 0)) * 4));
         sc.sync_bytes = sizeof(unsigned) * (GP_STATUS_WORDS + 2 * n_groups * GP_WG);
         sc.sync_words = reinterpret_cast<unsigned *>(take(sc.sync_bytes / sizeof(float)));
     } else if (kind == SHAKE_TRANSFORMER) {
@@ -1471,10 +1499,10 @@ bool gru_persistent_wanted() {
     return e == nullptr || e[0] != '0';
 }
 
-template <int G>
+template <int G, int MT>
 int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_groups, int n_sets, const ShakeScratch &sc,
                           hipStream_t s) {
-    auto kern = gru_big_persistent_kernel<G>;
+    auto kern = gru_big_persistent_kernel<G, MT>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         GP_LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
@@ -1484,24 +1512,25 @@ int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_group
     return SEDMI_OK;
 }
 
-// sets *used_persistent; the status word at sc.sync_words[0] is zeroed either way (the head kernel reads it)
+// the status word at sc.sync_words[0] is zeroed either way (the head kernel reads it)
 int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
     const long rows = n * T4;
     int rc;
     if ((rc = launch_linear("shake_gru_input_proj", m->wih, seq, sc.gi, rows, false, s))) return rc;
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.sync_words, 0, sc.sync_bytes, s));
-    // Small batches (minutes-long recordings: few clips, thousands of steps): the whole recurrence in one launch,
-    // W_hh resident in registers across 128 or 256 CUs.  Needs every workgroup resident at once (one per CU).
-    const int n_groups = static_cast<int>(sedmi::ceil_div(n, GP_CLIPS));
+    // Up to 192 clips: the whole recurrence in one launch, W_hh resident in registers across 128 or 256 CUs
+    // (needs every workgroup resident at once, one per CU).  Clips go in groups of 16 (up to 32 clips) or 32.
+    const int MT = n <= 32 ? 1 : 2;
+    const int n_groups = static_cast<int>(sedmi::ceil_div(n, 16 * MT));
     const int n_sets = n_groups >= 2 && 2 * 2 * GP_WG <= m->num_cus ? 2 : 1;
     const int G = static_cast<int>(sedmi::ceil_div(n_groups, n_sets));
     if (gru_persistent_wanted() && G <= GP_MAX_G && 2 * GP_WG * n_sets <= m->num_cus && T4 >= 2) {
         sedmi::ProfileScope prof("shake_gru_persistent", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
+        if (MT == 1) return launch_gru_persistent<1, 1>(m, n, T4, n_groups, n_sets, sc, s);
         switch (G) {
-            case 1: return launch_gru_persistent<1>(m, n, T4, n_groups, n_sets, sc, s);
-            case 2: return launch_gru_persistent<2>(m, n, T4, n_groups, n_sets, sc, s);
-            case 3: return launch_gru_persistent<3>(m, n, T4, n_groups, n_sets, sc, s);
-            default: return launch_gru_persistent<4>(m, n, T4, n_groups, n_sets, sc, s);
+            case 1: return launch_gru_persistent<1, 2>(m, n, T4, n_groups, n_sets, sc, s);
+            case 2: return launch_gru_persistent<2, 2>(m, n, T4, n_groups, n_sets, sc, s);
+            default: return launch_gru_persistent<3, 2>(m, n, T4, n_groups, n_sets, sc, s);
         }
     }
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));

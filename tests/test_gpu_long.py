@@ -133,9 +133,9 @@ def test_crnn_predict_files_60s_clips_n_fft_4096(tmp_path):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("n_clips,frames", [(1, 40), (16, 24), (17, 16), (64, 16), (128, 12), (130, 8)])
+@pytest.mark.parametrize("n_clips,frames", [(1, 40), (16, 24), (17, 16), (33, 16), (64, 12), (128, 12), (190, 8), (200, 8)])
 def test_shake_rcnn_recurrence_in_one_launch_agrees_with_per_step_launches(n_clips, frames, monkeypatch):
-    """The H = 1024 recurrence runs as one persistent launch for up to 128 clips (groups of 16 clips, one or two
+    """The H = 1024 recurrence runs as one persistent launch for up to 192 clips (groups of 16 or 32 clips, one or two
     clip sets, workgroups exchanging h through device memory every step) and as one launch per step beyond; both
     must give the oracle's logits.  SEDMI_SHAKE_GRU_PERSISTENT=0 selects the per-step kernel."""
     from oracle import shake
