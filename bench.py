@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=None, help="size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=["split_f16", "f32"], default=None,
                     help="CRNN arithmetic (default: the library default, split_f16)")
+    ap.add_argument("--no-exact-leg", action="store_true",
+                    help="crnn config: skip the extra exact-float32 pass behind the timed region (value_f32_exact)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: leave the all-gather of the frame predictions out of the step")
     args = ap.parse_args()
@@ -427,7 +429,7 @@ def main():
                 acceptance = dict(sample_clips=ns, frames_differing=n_diff, frames_differing_out_of_tolerance=n_bad,
                                   frames_within_tolerance_of_threshold=int(near.sum()), tolerance=1e-3, events_cpu=len(cpu_events),
                                   events_gpu=len(gpu_events), event_lists_identical=gpu_events == cpu_events)
-            if model.conv_precision == "split_f16":
+            if model.conv_precision == "split_f16" and not args.no_exact_leg:
                 # the same path in exact-float32 arithmetic, outside the timed region above
                 model.conv_precision = "f32"
                 pipe.run(y)

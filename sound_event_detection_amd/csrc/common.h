@@ -46,17 +46,16 @@ int upload(T **dev, const std::vector<T> &host) {
 
 // Optional per-launch timing (see sedmi_profile_enable in sedmi.h).
 bool profile_enabled();
-void profile_begin(const char *name, hipStream_t stream, double flops, double bytes);
-void profile_end(hipStream_t stream);
+long profile_begin(const char *name, hipStream_t stream, double flops, double bytes);   // record index or -1
+void profile_end(long index, hipStream_t stream);
 
 struct ProfileScope {
     hipStream_t stream;
-    bool on;
-    ProfileScope(const char *name, hipStream_t s, double flops, double bytes) : stream(s), on(profile_enabled()) {
-        if (on) profile_begin(name, s, flops, bytes);
-    }
+    long index;            // this scope's record; -1: profiling off or the events could not be created
+    ProfileScope(const char *name, hipStream_t s, double flops, double bytes)
+        : stream(s), index(profile_enabled() ? profile_begin(name, s, flops, bytes) : -1) {}
     ~ProfileScope() {
-        if (on) profile_end(stream);
+        if (index >= 0) profile_end(index, stream);
     }
 };
 

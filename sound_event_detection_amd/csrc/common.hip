@@ -31,17 +31,27 @@ std::vector<ProfileRecord> g_prof_records;
 
 bool profile_enabled() { return g_prof_on; }
 
-void profile_begin(const char *name, hipStream_t stream, double flops, double bytes) {
+// Returns the index of the new record, or -1 if its events could not be created (nothing is recorded then,
+// and a half-created pair is destroyed).
+long profile_begin(const char *name, hipStream_t stream, double flops, double bytes) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ProfileRecord r{name, flops, bytes, nullptr, nullptr};
-    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    if (hipEventCreate(&r.start) != hipSuccess) return -1;
+    if (hipEventCreate(&r.stop) != hipSuccess) {
+        (void)hipEventDestroy(r.start);
+        return -1;
+    }
     (void)hipEventRecord(r.start, stream);
     g_prof_records.push_back(r);
+    return static_cast<long>(g_prof_records.size()) - 1;
 }
 
-void profile_end(hipStream_t stream) {
+// Records the stop event of record `index` (as returned by profile_begin); ignores -1 and records that a
+// collect / enable has dropped in between.
+void profile_end(long index, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (!g_prof_records.empty()) (void)hipEventRecord(g_prof_records.back().stop, stream);
+    if (index >= 0 && static_cast<size_t>(index) < g_prof_records.size())
+        (void)hipEventRecord(g_prof_records[static_cast<size_t>(index)].stop, stream);
 }
 
 }  // namespace sedmi

@@ -513,12 +513,15 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
     SEDMI_REQUIRE(n_mels > 0 && n_mels <= 1024, "n_mels %d not in (0, 1024]", n_mels);
     SEDMI_REQUIRE(sr > 0, "sr must be positive");
 
+    // the device is queried before the plan exists, so that a failing query leaks nothing
+    int device = 0;
+    SEDMI_CHECK_HIP(hipGetDevice(&device));
+    hipDeviceProp_t prop;
+    SEDMI_CHECK_HIP(hipGetDeviceProperties(&prop, device));
     auto *p = new sedmi_mel_plan();
     p->sr = sr; p->n_fft = n_fft; p->win_length = win_length; p->hop = hop_length;
     p->n_mels = n_mels; p->n_bins = 1 + n_fft / 2; p->nnz_real = 0;
-    SEDMI_CHECK_HIP(hipGetDevice(&p->device));
-    hipDeviceProp_t prop;
-    SEDMI_CHECK_HIP(hipGetDeviceProperties(&prop, p->device));
+    p->device = device;
     p->num_cus = prop.multiProcessorCount;
 
     // periodic Hann, centred (librosa.util.pad_center)
