@@ -26,10 +26,12 @@
 //                        MODE_POOL_W5 / MODE_POOL_NCHW (BasicRCNN): plain conv + affine with the max-pool
 //                                   + ReLU that follows it in the epilogue.
 //   gemm_split_kernel    C = A.B + bias for the GRU input projection (M = clips*T', N = K = 6144).
-//   gru_big_step_kernel  one recurrence step for H = 1024: W_hh (25 MB for both directions) cannot
-//                        live in registers or LDS, so every step streams it from L2 / Infinity
-//                        Cache; a workgroup owns 32 clips x 32 hidden units x 3 gates, its four
-//                        waves split K and reduce through LDS, gate math included.
+//   gru_big_persistent_kernel  the whole H = 1024 recurrence in one launch (up to 192 clips): W_hh
+//                        (25 MB as f16 hi/lo planes) resident in the registers of 128 or 256
+//                        workgroups, h exchanged between them through device memory every step.
+//   gru_big_step_kernel  one recurrence step per launch for larger batches: every step streams
+//                        W_hh from L2 / Infinity Cache; a workgroup owns 32 clips x 32 hidden units
+//                        x 3 gates, its four waves split K and reduce through LDS, gate math included.
 //   ln_head_kernel       LayerNorm + LeakyReLU + Linear, one wave per frame.
 #include "common.h"
 
