@@ -930,6 +930,232 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
     }
 }
 
+// The same recurrence with the step number carried INSIDE the exchanged data instead of in separate flags.
+// An element of h travels as one 32-bit word: f16 hi half in the low 16 bits, f16 lo half in the high 16 bits,
+// whose least significant bit (2^-21 of h: below what the hi/lo pair resolves) is replaced by a tag = bit 1 of the
+// step number.  A buffer (parity s & 1) is rewritten every second step, so consecutive contents of a word carry
+// alternating tags; the array starts out as all ones (tag 1: the first write, step 0 or 1, carries tag 0).  Every
+// 32-bit word carries its own tag, so a reader can never take a half-updated 16-byte piece for a complete one.
+// A consumer simply loads its A-fragment words (sc1) until every tag shows the step it waits for: the payload
+// loads ARE the poll, and the producer side has no drain and no flag store (one memory round trip less on either
+// side of the hand-off).  The gate threads publish directly: a quad of lanes gathers its four words (DPP) and
+// its first lane stores them as one 16-byte write-through store, so there is one barrier per step and group (the
+// reduction buffer in LDS is double buffered).
+// exchange array, in uint4 units: [parity][dir][group][producer workgroup][clip 16 MT][4 quads of units]
+__host__ __device__ constexpr long gt_hx_index(int mt_tiles, int par, int dir, int n_groups, int gg, int wg) {
+    return (((static_cast<long>(par) * 2 + dir) * n_groups + gg) * GP_WG + wg) * (64 * mt_tiles);
+}
+
+template <int G, int MT>
+__global__ __launch_bounds__(512) void gru_big_tagged_kernel(
+    const float *__restrict__ gi, const uint4 *__restrict__ whh, float whh_oscale, const float *__restrict__ bhn,
+    float *__restrict__ out,
+    uint4 *hx,                          // exchange array (gt_hx_index), every byte 0xFF before the launch
+    unsigned *sync_words,               // [0]: status, zero before the launch
+    long n_clips, int T, int n_groups, int n_sets) {
+    constexpr int CLIPS = 16 * MT;
+    constexpr int RED_FLOATS = 8 * 3 * MT * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *red_all = reinterpret_cast<float *>(smem);                   // [2][wave][gate][mt][clip 16][unit 16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int wg = blockIdx.x, dir = blockIdx.y, set = blockIdx.z;
+    gu32 *status = (gu32 *)sync_words;
+
+    f16x8 wh[3][4], wl[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int ks16 = 2 * (4 * wave + s4) + (kg >> 1);
+            const int col = (wg >> 1) * 96 + q * 32 + (wg & 1) * 16 + n16;
+            const uint4 *p = whh + ((static_cast<long>(dir) * (GB_H / 16) + ks16) * 2 * (3 * GB_H) + col) * 2 + (kg & 1);
+            wh[q][s4] = __builtin_bit_cast(f16x8, p[0]);
+            wl[q][s4] = __builtin_bit_cast(f16x8, p[2 * 3 * GB_H]);
+        }
+
+    const bool gate_thread = tid < 256;
+    const int gc = (tid >> 4) & 15, gn = tid & 15, j = wg * GP_U + gn;
+    const float b_hn = bhn[dir * GB_H + j];
+    float hprev[G][MT], gcur[G][MT][3], gnext[G][MT][3];
+    int clip_of[G][MT];
+    bool live[G][MT];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int gg = set + n_sets * g;
+            const long b = static_cast<long>(gg) * CLIPS + 16 * mt + gc;
+            live[g][mt] = gate_thread && gg < n_groups && b < n_clips;
+            clip_of[g][mt] = live[g][mt] ? static_cast<int>(b) : -1;
+            hprev[g][mt] = 0.f;
+            const long t0 = dir ? T - 1 : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                gnext[g][mt][q] = live[g][mt] ? gi[((b * T + t0) * 2 + dir) * (3L * GB_H) + q * GB_H + j] : 0.f;
+                gcur[g][mt][q] = 0.f;
+            }
+        }
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        hx, 0, static_cast<int>(gt_hx_index(MT, 2, 0, n_groups, 0, 0) * 16), 0x00020000);
+    bool gave_up = false;
+    int it = 0;                                               // (step, group) iterations done: selects the LDS buffer
+
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        const long t = dir ? T - 1 - s : s, tn = dir ? T - 2 - s : s + 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gg = set + n_sets * g;
+            if (gg >= n_groups) continue;                     // uniform over the workgroup
+            float *red = red_all + (it & 1) * RED_FLOATS;
+            ++it;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gcur[g][mt][q] = gnext[g][mt][q];
+            f32x4g acc[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[mt][q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+            if (s > 0) {
+                // this lane's words of h_{t-1}: row = clip 16 mt + n16, k = 128 wave + 32 s4 + 8 kg .. + 7 -> producer
+                // workgroup 8 wave + 2 s4 + kg / 2, its quads 2 (kg & 1) and 2 (kg & 1) + 1: 32 contiguous bytes
+                const int par = (s - 1) & 1;
+                const unsigned want = ((static_cast<unsigned>(s - 1) >> 1) & 1u) ? 0x00010000u : 0u;
+                u32x4v wa[MT][4], wb[MT][4];
+                unsigned spins = 0;
+                if (MT > 1) {
+                    // large groups: wait on ONE piece per lane first (the last one its producers write), so that the
+                    // waiting costs the memory system 16 bytes per lane and poll instead of 256
+                    const int wgp = 8 * wave + 2 * 3 + (kg >> 1);
+                    const int o = static_cast<int>((gt_hx_index(MT, par, dir, n_groups, gg, wgp) + (16 * (MT - 1) + n16) * 4 +
+                                                    2 * (kg & 1) + 1) * 16);
+                    while (!gave_up) {
+                        const u32x4v probe = __builtin_amdgcn_raw_buffer_load_b128(hrs, o, 0, 16);
+                        const unsigned pa = probe[0] & probe[1] & probe[2] & probe[3], po = probe[0] | probe[1] | probe[2] | probe[3];
+                        const bool ok = want ? (pa & 0x00010000u) != 0u : (po & 0x00010000u) == 0u;
+                        if (__all(ok)) break;
+                        if (++spins > GP_SPIN_LIMIT) {
+                            gave_up = true;
+                            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                while (true) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int wgp = 8 * wave + 2 * s4 + (kg >> 1);
+                            const int o = static_cast<int>((gt_hx_index(MT, par, dir, n_groups, gg, wgp) + (16 * mt + n16) * 4 +
+                                                            2 * (kg & 1)) * 16);
+                            wa[mt][s4] = __builtin_amdgcn_raw_buffer_load_b128(hrs, o, 0, 16);
+                            wb[mt][s4] = __builtin_amdgcn_raw_buffer_load_b128(hrs, o + 16, 0, 16);
+                        }
+                    unsigned all_and = 0xffffffffu, all_or = 0u;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                all_and &= wa[mt][s4][e] & wb[mt][s4][e];
+                                all_or |= wa[mt][s4][e] | wb[mt][s4][e];
+                            }
+                    const bool ok = want ? (all_and & 0x00010000u) != 0u : (all_or & 0x00010000u) == 0u;
+                    if (__all(ok) || gave_up) break;
+                    if (++spins > GP_SPIN_LIMIT) {
+                        gave_up = true;
+                        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        // de-interleave: word = hi | lo << 16 -> fragment words (k, k + 1) of the hi and lo planes
+                        u32x4v fh, fl;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            fh[e] = __builtin_amdgcn_perm(wa[mt][s4][2 * e + 1], wa[mt][s4][2 * e], 0x05040100u);
+                            fl[e] = __builtin_amdgcn_perm(wa[mt][s4][2 * e + 1], wa[mt][s4][2 * e], 0x07060302u) & 0xfffefffeu;
+                            fh[2 + e] = __builtin_amdgcn_perm(wb[mt][s4][2 * e + 1], wb[mt][s4][2 * e], 0x05040100u);
+                            fl[2 + e] = __builtin_amdgcn_perm(wb[mt][s4][2 * e + 1], wb[mt][s4][2 * e], 0x07060302u) & 0xfffefffeu;
+                        }
+                        const f16x8 ah = __builtin_bit_cast(f16x8, fh), al = __builtin_bit_cast(f16x8, fl);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[q][s4], acc[mt][q], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[q][s4], acc[mt][q], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[q][s4], acc[mt][q], 0, 0, 0);
+                    }
+            }
+            // the next step's gate inputs, requested behind the exchange loads
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (live[g][mt] && s + 1 < T) {
+                    const float *gp = gi + ((static_cast<long>(clip_of[g][mt]) * T + tn) * 2 + dir) * (3L * GB_H) + j;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) gnext[g][mt][q] = gp[q * GB_H];
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        red[(((wave * 3 + q) * MT + mt) * 16 + 4 * kg + i) * 16 + n16] = acc[mt][q][i];
+            __syncthreads();
+            if (gate_thread) {
+                const unsigned tag = ((static_cast<unsigned>(s) >> 1) & 1u) << 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float gh[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) sum += red[((w * 3 + q) * MT + mt) * 256 + tid];
+                        gh[q] = sum * whh_oscale;
+                    }
+                    const float rg = sigmoidf_fast(gcur[g][mt][0] + gh[0]);
+                    const float zg = sigmoidf_fast(gcur[g][mt][1] + gh[1]);
+                    const float ng = tanhf_fast(fmaf(rg, gh[2] + b_hn, gcur[g][mt][2]));
+                    const float hv = fmaf(zg, hprev[g][mt] - ng, ng);             // (1 - z) * n + z * h
+                    hprev[g][mt] = hv;
+                    if (live[g][mt]) out[(static_cast<long>(clip_of[g][mt]) * T + t) * (2L * GB_H) + dir * GB_H + j] = hv;
+                    if (s + 1 < T) {
+                        _Float16 hi, lo;
+                        split_f16(hv, hi, lo);
+                        const unsigned word = static_cast<unsigned>(__builtin_bit_cast(unsigned short, hi)) |
+                                              ((static_cast<unsigned>(__builtin_bit_cast(unsigned short, lo)) << 16) & 0xfffe0000u) | tag;
+                        // lanes 4 k .. 4 k + 3 hold units 4 k .. 4 k + 3 of one clip: the first lane of the quad stores all four
+                        u32x4v v;
+                        v[0] = word;
+                        v[1] = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0x55, 0xf, 0xf, false));
+                        v[2] = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0xaa, 0xf, 0xf, false));
+                        v[3] = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0xff, 0xf, 0xf, false));
+                        if ((gn & 3) == 0) {
+                            const int o = static_cast<int>((gt_hx_index(MT, s & 1, dir, n_groups, gg, wg) + (16 * mt + gc) * 4 + (gn >> 2)) * 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, hrs, o, 0, 16);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // [LayerNorm(D) -> LeakyReLU(0.01) ->] Linear(D, n_cls): one wave per row
 // ---------------------------------------------------------------------------
@@ -1501,9 +1727,31 @@ bool gru_persistent_wanted() {
     return e == nullptr || e[0] != '0';
 }
 
+// Which hand-off the persistent recurrence uses: separate flags (gru_big_persistent_kernel) or step tags inside
+// the data (gru_big_tagged_kernel).  Measured per step: 4 clips 4.3 us with flags / 3.6 with tags, 64 clips 6.4 /
+// 5.9, 128 clips (two groups per workgroup) 6.8 / 8.9 -- tags when a workgroup serves one group per step, flags
+// when it serves several.  SEDMI_SHAKE_GRU_EXCHANGE=flag|tag overrides (tests run both).
+bool gru_exchange_by_flags(int groups_per_workgroup) {
+    const char *e = std::getenv("SEDMI_SHAKE_GRU_EXCHANGE");
+    if (e != nullptr && e[0] == 'f') return true;
+    if (e != nullptr && e[0] == 't') return false;
+    return groups_per_workgroup > 1;
+}
+
 template <int G, int MT>
 int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_groups, int n_sets, const ShakeScratch &sc,
                           hipStream_t s) {
+    if (!gru_exchange_by_flags(G)) {
+        auto kern = gru_big_tagged_kernel<G, MT>;
+        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            GP_LDS_BYTES));
+        SEDMI_CHECK_HIP(hipMemsetAsync(sc.hx, 0xff, static_cast<size_t>(gt_hx_index(MT, 2, 0, n_groups, 0, 0)) * 16, s));
+        hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
+                           reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words,
+                           n, T4, n_groups, n_sets);
+        SEDMI_CHECK_LAUNCH();
+        return SEDMI_OK;
+    }
     auto kern = gru_big_persistent_kernel<G, MT>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         GP_LDS_BYTES));

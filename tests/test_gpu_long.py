@@ -137,19 +137,25 @@ def test_crnn_predict_files_60s_clips_n_fft_4096(tmp_path):
 def test_shake_rcnn_recurrence_in_one_launch_agrees_with_per_step_launches(n_clips, frames, monkeypatch):
     """The H = 1024 recurrence runs as one persistent launch for up to 192 clips (groups of 16 or 32 clips, one or two
     clip sets, workgroups exchanging h through device memory every step) and as one launch per step beyond; both
-    must give the oracle's logits.  SEDMI_SHAKE_GRU_PERSISTENT=0 selects the per-step kernel."""
+    must give the oracle's logits.  SEDMI_SHAKE_GRU_PERSISTENT=0 selects the per-step kernel,
+    SEDMI_SHAKE_GRU_EXCHANGE=flag|tag the persistent kernel's hand-off protocol."""
     from oracle import shake
     m, sd = _shake("rcnn")
     x = torch.from_numpy(synth.synth_shake_feats(60 + n_clips, n_clips, frames))
     al = [0.45, 0.25, 0.65]
     want = shake.shake_rcnn_forward(sd, x, al).numpy()
     monkeypatch.setenv("SEDMI_SHAKE_GRU_PERSISTENT", "1")
-    one = m(x.cuda(), al).cpu().numpy()
-    again = m(x.cuda(), al).cpu().numpy()
+    got = {}
+    for exchange in ("flag", "tag"):                    # the two hand-off protocols of the persistent kernel
+        monkeypatch.setenv("SEDMI_SHAKE_GRU_EXCHANGE", exchange)
+        got[exchange] = m(x.cuda(), al).cpu().numpy()
+        again = m(x.cuda(), al).cpu().numpy()
+        assert np.isfinite(got[exchange]).all()
+        assert np.array_equal(got[exchange], again)     # deterministic: no atomics, fixed reduction order
+        np.testing.assert_allclose(got[exchange], want, rtol=0, atol=ATOL_LOGITS)
+    monkeypatch.delenv("SEDMI_SHAKE_GRU_EXCHANGE")
     monkeypatch.setenv("SEDMI_SHAKE_GRU_PERSISTENT", "0")
     per_step = m(x.cuda(), al).cpu().numpy()
-    assert np.isfinite(one).all()
-    assert np.array_equal(one, again)                   # deterministic: no atomics, fixed reduction order
-    np.testing.assert_allclose(one, want, rtol=0, atol=ATOL_LOGITS)
     np.testing.assert_allclose(per_step, want, rtol=0, atol=ATOL_LOGITS)
-    np.testing.assert_allclose(one, per_step, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got["flag"], per_step, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got["tag"], got["flag"], rtol=0, atol=2e-4)
