@@ -1275,38 +1275,63 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
         for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
+    // the K / V rows of a key block are requested one block ahead (into registers) and split into the LDS planes at
+    // the top of the next iteration: their latency passes under the current block's products.
+    // K: thread -> (key i >> 5, dims 4 (i & 31) .. + 3), one 8-byte LDS write per plane, lanes contiguous.
+    // V: thread -> (key PAIR (tid >> 5) + 8 j, dims (tid & 31) + 32 e): a pair of neighbouring keys is a pair of
+    // neighbouring slots of V^T, so one packed split gives one 32-bit LDS write per dim and plane, and the 32 lanes of
+    // a half wave write rows 80 bytes apart (16 banks, two lanes each) -- with four consecutive dims per thread the
+    // rows were 320 bytes apart and every 2-byte write was a 16-way bank conflict.
+    float4 kreg[4];
+    float vreg[2][4][2];                // [j][e][key of the pair]
+    const int vlq = tid & 31, vpair = tid >> 5;
+    auto load_kv = [&](int kb0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, key = i >> 5, c4 = (i & 31) * 4;
+            kreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kb0 + key < T) kreg[j] = *reinterpret_cast<const float4 *>(base + static_cast<long>(kb0 + key) * 3072 + 1024 + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int key = 2 * (vpair + 8 * j) + kk;
+                const bool ok = kb0 + key < T;
+                const float *p = base + static_cast<long>(ok ? kb0 + key : 0) * 3072 + 2048 + vlq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vreg[j][e][kk] = ok ? p[32 * e] : 0.f;
+            }
+    };
+    load_kv(0);
     for (int kb0 = 0; kb0 < T; kb0 += AT_KB) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = tid + 256 * j, key = i >> 5, c4 = (i & 31) * 4;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (kb0 + key < T) {
-                const float *p = base + static_cast<long>(kb0 + key) * 3072 + c4;
-                kv = *reinterpret_cast<const float4 *>(p + 1024);
-                vv = *reinterpret_cast<const float4 *>(p + 2048);
-            }
             uint2 hi, lo;
-            split2_f16(kv.x, kv.y, hi.x, lo.x);
-            split2_f16(kv.z, kv.w, hi.y, lo.y);
+            split2_f16(kreg[j].x, kreg[j].y, hi.x, lo.x);
+            split2_f16(kreg[j].z, kreg[j].w, hi.y, lo.y);
             *reinterpret_cast<uint2 *>(kh + key * AT_KSB + c4 * 2) = hi;
             *reinterpret_cast<uint2 *>(kl + key * AT_KSB + c4 * 2) = lo;
-            // key = acc_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h sits in slot 16 (r >> 3) + 8 h + (r & 7) of V^T's rows
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // key = acc_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h sits in slot 16 (r >> 3) + 8 h + (r & 7) of V^T's rows;
+            // an even key and its successor are an even slot and its successor
+            const int key = 2 * (vpair + 8 * j);
             const int h = (key >> 2) & 1, r = (key & 3) + 4 * (key >> 3);
             const int slot = 16 * (r >> 3) + 8 * h + (r & 7);
-            split2_f16(vv.x, vv.y, hi.x, lo.x);
-            split2_f16(vv.z, vv.w, hi.y, lo.y);
-            char *ph = vth + c4 * AT_VSB + slot * 2, *pl = vtl + c4 * AT_VSB + slot * 2;
-            *reinterpret_cast<unsigned short *>(ph) = static_cast<unsigned short>(hi.x);
-            *reinterpret_cast<unsigned short *>(ph + AT_VSB) = static_cast<unsigned short>(hi.x >> 16);
-            *reinterpret_cast<unsigned short *>(ph + 2 * AT_VSB) = static_cast<unsigned short>(hi.y);
-            *reinterpret_cast<unsigned short *>(ph + 3 * AT_VSB) = static_cast<unsigned short>(hi.y >> 16);
-            *reinterpret_cast<unsigned short *>(pl) = static_cast<unsigned short>(lo.x);
-            *reinterpret_cast<unsigned short *>(pl + AT_VSB) = static_cast<unsigned short>(lo.x >> 16);
-            *reinterpret_cast<unsigned short *>(pl + 2 * AT_VSB) = static_cast<unsigned short>(lo.y);
-            *reinterpret_cast<unsigned short *>(pl + 3 * AT_VSB) = static_cast<unsigned short>(lo.y >> 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, lo;
+                split2_f16(vreg[j][e][0], vreg[j][e][1], hi, lo);
+                *reinterpret_cast<unsigned *>(vth + (vlq + 32 * e) * AT_VSB + slot * 2) = hi;
+                *reinterpret_cast<unsigned *>(vtl + (vlq + 32 * e) * AT_VSB + slot * 2) = lo;
+            }
         }
         __syncthreads();
+        if (kb0 + AT_KB < T) load_kv(kb0 + AT_KB);
         // S^T[key][query]: A row = key col32, B column = query col32
         f32x16 sc;
 #pragma unroll
@@ -1336,11 +1361,14 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
         }
         psum += __shfl_xor(psum, 32);
         l = fmaf(l, corr, psum);
+        const bool moved = m_new != m;
         m = m_new;
+        if (__any(moved)) {                          // the running maximum moved for some query of the wave: rescale
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+                for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+        }
         // B operand of O^T: this lane's probabilities, registers 8 ks .. 8 ks + 7 = key slots 16 ks + 8 half + 0..7
         f16x8 pph[2], ppl[2];
 #pragma unroll
