@@ -295,7 +295,7 @@ typedef struct sedmi_basic_rcnn sedmi_basic_rcnn;
 
 typedef struct sedmi_basic_rcnn_weights {
     int n_class;
-    int frequency_dim;                  /* F: feature width, even, >= 10 (64 in the reference) */
+    int frequency_dim;                  /* F: feature width, >= 10 (64 in the reference); GRU input 128 * ((F - 8) / 2) */
     const float *conv_w[3], *conv_b[3];
     const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
     const float *fc_w, *fc_b;

@@ -13,10 +13,12 @@
 //     registers; the three stages exchange data through a per-wave LDS
 //     scratch (three transposes), then each lane untangles bin pairs
 //     (k, NC-k) of the real spectrum and leaves |X|^2 in the same scratch;
-//   * the wave then applies the filterbank itself as a sparse contraction,
-//     lane = filter (every filter is a short contiguous run of bins: 2020
-//     non-zeros of 131200 for 128 mels at n_fft 2048), eight bins in flight
-//     per lane, weights in LDS with run starts skewed across bank groups;
+//   * the wave then applies the filterbank itself as a sparse contraction
+//     (every filter is a short contiguous run of bins: 2020 non-zeros of
+//     131200 for 128 mels at n_fft 2048), lane = a PAIR of filters (a narrow
+//     low one with a wide high one, so that all lanes carry about the same
+//     number of bins), eight bins in flight per lane, weights in LDS with run
+//     starts skewed across bank groups;
 //   * a wave never waits for another wave: no workgroup barrier in the frame
 //     loop, LDS = 8.7 KB of scratch per wave + the weights, which leaves room
 //     for three waves per SIMD to cover the LDS round trips;
@@ -42,10 +44,15 @@ struct MelArgs {
     const float2 *tw_post;   // [NC/2+1]  exp(-2 pi i k / (2 NC))
     int zlo, zhi;            // complex indices with a non-zero window tap: [zlo, zhi)
     int n_mels;
-    const int *mel_start;    // first bin of each filter
-    const int *mel_len;      // number of bins, rounded up to a multiple of 8
-    const int *mel_ptr;      // offset into mel_w (a multiple of 4, skewed against LDS bank conflicts)
-    const float *mel_w;      // every filter's run of weights, zero-padded to its rounded length
+    // Filters are applied in PAIRS, one pair per lane: filter widths grow with frequency (6 bins at the bottom,
+    // ~70 at the top for 128 mels at n_fft 2048), so lane = filter leaves most lanes idle while the widest
+    // filter of the pass finishes; pairing filter l of a chunk of 128 with filter 127 - l gives every lane about
+    // the same number of bins.  Per pair (5 ints): first bin of A, bins of A (rounded up to a multiple of 8),
+    // first bin of B minus the rounded bins of A, rounded bins of A and B together, offset of the pair's
+    // weights (A's run, then B's) in mel_w.
+    const int *mel_meta;
+    int n_pairs;             // 64 per chunk of 128 filters
+    const float *mel_w;      // every pair's weights, each run zero-padded to its rounded length
     int nnz;                 // floats in mel_w
     float *out;
     int flags;
@@ -147,7 +154,7 @@ struct MelGeom {
 // others are compile-time zeros, are never loaded, and their butterflies fold away.
 //
 // A wave is self-contained: it transforms a frame, leaves the power spectrum in its own LDS scratch
-// and applies the filterbank to it (lane = filter), so there is no workgroup barrier in the frame
+// and applies the filterbank to it (lane = a pair of filters), so there is no workgroup barrier in the frame
 // loop and the LDS footprint is the scratch alone (three 4-wave workgroups per CU at n_fft 2048:
 // three waves per SIMD to cover the LDS round trips of the transposes).
 template <int R1, int WAVES, int ROW0, int NROW>
@@ -162,16 +169,12 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform by construction; tells the compiler so
     float2 *scr = scr_all + wave * G::SCR;
     float *melw = reinterpret_cast<float *>(smem + sizeof(float2) * G::SCR * WAVES);
-    int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));
+    int *melmeta = reinterpret_cast<int *>(melw + ((a.nnz + 3) & ~3));       // [n_pairs][5]
     float *pw = reinterpret_cast<float *>(scr);        // power spectrum [NC + 1], aliases the scratch
 
     // ---- one-time per-workgroup / per-lane constants ------------------------
     for (int i = tid; i < a.nnz; i += WAVES * 64) melw[i] = a.mel_w[i];
-    for (int i = tid; i < a.n_mels; i += WAVES * 64) {
-        melmeta[3 * i + 0] = a.mel_start[i];
-        melmeta[3 * i + 1] = a.mel_len[i];
-        melmeta[3 * i + 2] = a.mel_ptr[i];
-    }
+    for (int i = tid; i < 5 * a.n_pairs; i += WAVES * 64) melmeta[i] = a.mel_meta[i];
 
     float w0[NROW], w1[NROW];      // window taps of this lane's samples
     float t1r[R1], t1i[R1];        // stage-1 twiddles  W_NC^(lane * k1), k1 = bitrev(p)
@@ -386,42 +389,62 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
         }
         if (lane < 8) pw[NC + 1 + lane] = 0.f;
         wave_lds_fence();
-        // ---- sparse mel projection: lane = filter -----------------------------
+        // ---- sparse mel projection: lane = a pair of filters -----------------------
         // weight runs are zero-padded to a multiple of 8 on the host, so eight bins go in flight together
         // (the reads past a filter's end meet zero weights; pw carries 8 floats of zero padding)
-        for (int m = lane; m < a.n_mels; m += 64) {
-            const int start = melmeta[3 * m + 0], len = melmeta[3 * m + 1], ptr = melmeta[3 * m + 2];
-            float acc0 = 0.f, acc1 = 0.f;
-            for (int i = 0; i < len; i += 8) {
+        for (int mp = lane; mp < a.n_pairs; mp += 64) {
+            const int chunk = mp >> 6;
+            const int start_a = melmeta[5 * mp + 0], len_a = melmeta[5 * mp + 1], base_b = melmeta[5 * mp + 2];
+            const int total = melmeta[5 * mp + 3], ptr = melmeta[5 * mp + 4];
+            float acc_a = 0.f, acc_b = 0.f;
+            for (int i = 0; i < total; i += 8) {
+                const bool in_a = i < len_a;
                 const float4 wa = *reinterpret_cast<const float4 *>(melw + ptr + i);
                 const float4 wb = *reinterpret_cast<const float4 *>(melw + ptr + i + 4);
-                const float *pp = pw + start + i;
+                const float *pp = pw + (in_a ? start_a : base_b) + i;
                 const float p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4], p5 = pp[5], p6 = pp[6], p7 = pp[7];
-                acc0 = fmaf(wa.x, p0, acc0); acc1 = fmaf(wa.y, p1, acc1);
-                acc0 = fmaf(wa.z, p2, acc0); acc1 = fmaf(wa.w, p3, acc1);
-                acc0 = fmaf(wb.x, p4, acc0); acc1 = fmaf(wb.y, p5, acc1);
-                acc0 = fmaf(wb.z, p6, acc0); acc1 = fmaf(wb.w, p7, acc1);
+                float s0 = wa.x * p0, s1 = wa.y * p1;
+                s0 = fmaf(wa.z, p2, s0); s1 = fmaf(wa.w, p3, s1);
+                s0 = fmaf(wb.x, p4, s0); s1 = fmaf(wb.y, p5, s1);
+                s0 = fmaf(wb.z, p6, s0); s1 = fmaf(wb.w, p7, s1);
+                const float sum8 = s0 + s1;
+                acc_a += in_a ? sum8 : 0.f;
+                acc_b += in_a ? 0.f : sum8;
             }
-            float acc = acc0 + acc1;
-            if (a.flags & SEDMI_MEL_LOG) acc = 10.0f * log10f(fmaxf(acc, 1e-10f));
-            if (a.flags & SEDMI_MEL_NORMALISE) acc = (acc - a.mean[m]) * a.istd[m];
-            const int j = t & 3, pass = m >> 6;
-            if (pass < 2) {
+            // chunk of C filters starting at 128 chunk: A = first + lane, B = first + C - 1 - lane
+            const int first = 128 * chunk, C = a.n_mels - first < 128 ? a.n_mels - first : 128;
+            const int l = mp & 63;
+            const int m_a = first + l, m_b = first + C - 1 - l;
+            const bool has_a = l < (C + 1) / 2, has_b = l < C / 2;      // an odd chunk's middle filter has no partner
+            if (a.flags & SEDMI_MEL_LOG) {
+                acc_a = 10.0f * log10f(fmaxf(acc_a, 1e-10f));
+                acc_b = 10.0f * log10f(fmaxf(acc_b, 1e-10f));
+            }
+            if (a.flags & SEDMI_MEL_NORMALISE) {
+                if (has_a) acc_a = (acc_a - a.mean[m_a]) * a.istd[m_a];
+                if (has_b) acc_b = (acc_b - a.mean[m_b]) * a.istd[m_b];
+            }
+            if (chunk == 0) {
+                const int j4 = t & 3;
 #pragma unroll
-                for (int pp2 = 0; pp2 < 2; ++pp2)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        if (pp2 == pass && jj == j) keep[pp2][jj] = acc;
+                for (int jj = 0; jj < 4; ++jj)
+                    if (jj == j4) {
+                        keep[0][jj] = acc_a;
+                        keep[1][jj] = acc_b;
+                    }
             } else {
-                a.out[(clip * a.n_mels + m) * static_cast<long>(a.T) + t] = acc;
+                if (has_a) a.out[(clip * a.n_mels + m_a) * static_cast<long>(a.T) + t] = acc_a;
+                if (has_b) a.out[(clip * a.n_mels + m_b) * static_cast<long>(a.T) + t] = acc_b;
             }
         }
         if ((t & 3) == 3 || t + 1 >= a.T) {            // last frame of its group of four (or of the clip)
             const int t0 = t & ~3, nl = t - t0 + 1;
+            const int C = a.n_mels < 128 ? a.n_mels : 128;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
-                const int m = pass * 64 + lane;
-                if (m < a.n_mels) {
+                const int m = pass == 0 ? lane : C - 1 - lane;
+                const bool has = pass == 0 ? lane < (C + 1) / 2 : lane < C / 2;
+                if (has) {
                     float *dst = a.out + (clip * a.n_mels + m) * static_cast<long>(a.T) + t0;
                     if (nl == 4) {                     // rows are T floats apart: 4-byte aligned only
                         *reinterpret_cast<Float4U *>(dst) = Float4U{keep[pass][0], keep[pass][1], keep[pass][2], keep[pass][3]};
@@ -440,7 +463,8 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
 template <int R1, int WAVES>
 size_t mel_lds_bytes(int n_mels, int nnz) {
     using G = MelGeom<R1>;
-    return sizeof(float2) * G::SCR * WAVES + sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 3 * n_mels;
+    const int n_pairs = 64 * ((n_mels + 127) / 128);
+    return sizeof(float2) * G::SCR * WAVES + sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 5 * n_pairs;
 }
 
 // float64 -> per-bin statistics for the optional normalisation stage
@@ -496,7 +520,8 @@ struct sedmi_mel_plan {
     std::vector<float> fb_dense;   // host copy [n_mels, n_bins]
     float *d_win = nullptr;
     float2 *d_tw_nc = nullptr, *d_tw_post = nullptr;
-    int *d_start = nullptr, *d_len = nullptr, *d_ptr = nullptr;
+    int *d_meta = nullptr;         // [n_pairs][5], see MelArgs
+    int n_pairs = 0;
     float *d_w = nullptr;
 };
 
@@ -555,9 +580,7 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
     for (int i = 0; i < n_mels + 2; ++i)
         mel_f[i] = mel_to_hz(i == n_mels + 1 ? mmax : i * mstep + mmin);
     p->fb_dense.assign(static_cast<size_t>(n_mels) * nb, 0.f);
-    std::vector<int> start(n_mels), len(n_mels), ptr(n_mels);
-    std::vector<float> wsp;
-    unsigned used_groups = 0;
+    std::vector<int> start(n_mels), len(n_mels);
     for (int i = 0; i < n_mels; ++i) {
         const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
         const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
@@ -574,25 +597,41 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
         }
         start[i] = first < 0 ? 0 : first;
         len[i] = first < 0 ? 0 : last - first + 1;
-        // the 16-byte weight reads that 16 neighbouring lanes (= filters 16 j .. 16 j + 15) issue together
-        // should fall into 16 different groups of four LDS banks: start each run at the first multiple of
-        // four floats whose bank group no other filter of its 16-group uses yet
-        if (i % 16 == 0) used_groups = 0;
+        p->nnz_real += len[i];
+    }
+    // one run of weights per PAIR of filters (lane l of a chunk of C <= 128 filters: filters l and C - 1 - l)
+    p->n_pairs = 64 * ((n_mels + 127) / 128);
+    std::vector<int> meta(static_cast<size_t>(5) * p->n_pairs, 0);
+    std::vector<float> wsp;
+    unsigned used_groups = 0;
+    for (int mp = 0; mp < p->n_pairs; ++mp) {
+        const int first = 128 * (mp / 64), C = std::min(128, n_mels - first), l = mp % 64;
+        const int fa = l < (C + 1) / 2 ? first + l : -1;
+        const int fb = l < C / 2 ? first + C - 1 - l : -1;
+        const int la = fa >= 0 ? (len[fa] + 7) & ~7 : 0, lb = fb >= 0 ? (len[fb] + 7) & ~7 : 0;
+        // the 16-byte weight reads that 16 neighbouring lanes issue together should fall into 16 different groups
+        // of four LDS banks: start each run at the first multiple of four floats whose bank group no other pair of
+        // its 16-group uses yet
+        if (mp % 16 == 0) used_groups = 0;
         while (wsp.size() % 4) wsp.push_back(0.f);
         while (used_groups >> ((wsp.size() / 4) % 16) & 1u) wsp.insert(wsp.end(), 4, 0.f);
         used_groups |= 1u << ((wsp.size() / 4) % 16);
-        ptr[i] = static_cast<int>(wsp.size());
-        p->nnz_real += len[i];
-        for (int k = 0; k < len[i]; ++k) wsp.push_back(p->fb_dense[static_cast<size_t>(i) * nb + start[i] + k]);
-        len[i] = (len[i] + 7) & ~7;                     // the kernel consumes a filter's run eight bins at a time
-        while (wsp.size() < static_cast<size_t>(ptr[i] + len[i])) wsp.push_back(0.f);
+        const int ptr = static_cast<int>(wsp.size());
+        for (int k = 0; k < la; ++k)
+            wsp.push_back(k < len[fa] ? p->fb_dense[static_cast<size_t>(fa) * nb + start[fa] + k] : 0.f);
+        for (int k = 0; k < lb; ++k)
+            wsp.push_back(k < len[fb] ? p->fb_dense[static_cast<size_t>(fb) * nb + start[fb] + k] : 0.f);
+        meta[5 * mp + 0] = fa >= 0 ? start[fa] : 0;
+        meta[5 * mp + 1] = la;
+        meta[5 * mp + 2] = (fb >= 0 ? start[fb] : 0) - la;
+        meta[5 * mp + 3] = la + lb;
+        meta[5 * mp + 4] = ptr;
     }
     p->nnz = static_cast<int>(wsp.size());
 
     int rc;
     if ((rc = sedmi::upload(&p->d_win, win)) || (rc = sedmi::upload(&p->d_tw_nc, tw_nc)) ||
-        (rc = sedmi::upload(&p->d_tw_post, tw_post)) || (rc = sedmi::upload(&p->d_start, start)) ||
-        (rc = sedmi::upload(&p->d_len, len)) || (rc = sedmi::upload(&p->d_ptr, ptr)) ||
+        (rc = sedmi::upload(&p->d_tw_post, tw_post)) || (rc = sedmi::upload(&p->d_meta, meta)) ||
         (rc = sedmi::upload(&p->d_w, wsp))) {
         sedmi_mel_plan_destroy(p);
         return rc;
@@ -604,7 +643,7 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
 int sedmi_mel_plan_destroy(sedmi_mel_plan *p) {
     if (!p) return SEDMI_OK;
     (void)hipFree(p->d_win); (void)hipFree(p->d_tw_nc); (void)hipFree(p->d_tw_post);
-    (void)hipFree(p->d_start); (void)hipFree(p->d_len); (void)hipFree(p->d_ptr); (void)hipFree(p->d_w);
+    (void)hipFree(p->d_meta); (void)hipFree(p->d_w);
     delete p;
     return SEDMI_OK;
 }
@@ -661,7 +700,7 @@ int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, 
     MelArgs a{};
     a.y = y; a.n_samples = n_samples; a.T = static_cast<int>(T); a.hop = p->hop; a.n_fft = p->n_fft;
     a.win = p->d_win; a.tw_nc = p->d_tw_nc; a.tw_post = p->d_tw_post; a.zlo = p->zlo; a.zhi = p->zhi;
-    a.n_mels = p->n_mels; a.mel_start = p->d_start; a.mel_len = p->d_len; a.mel_ptr = p->d_ptr;
+    a.n_mels = p->n_mels; a.mel_meta = p->d_meta; a.n_pairs = p->n_pairs;
     a.mel_w = p->d_w; a.nnz = p->nnz; a.out = out; a.flags = flags; a.mean = mean; a.istd = istd;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->n_fft) {

@@ -2216,8 +2216,8 @@ int sedmi_basic_rcnn_create(sedmi_basic_rcnn **out, const sedmi_basic_rcnn_weigh
     SEDMI_REQUIRE(out && w, "null argument");
     *out = nullptr;
     SEDMI_REQUIRE(w->n_class > 0 && w->n_class <= 4096, "n_class %d out of range", w->n_class);
-    SEDMI_REQUIRE(w->frequency_dim >= 10 && w->frequency_dim % 2 == 0 && w->frequency_dim <= 4096,
-                  "frequency_dim %d: need an even value >= 10", w->frequency_dim);
+    // odd widths are floored by the last max-pool like the reference's ((F - 8) // 2, models.py:36)
+    SEDMI_REQUIRE(w->frequency_dim >= 10 && w->frequency_dim <= 4096, "frequency_dim %d: need 10 .. 4096", w->frequency_dim);
     for (int i = 0; i < 3; ++i) SEDMI_REQUIRE(w->conv_w[i] && w->conv_b[i], "null conv weight pointer");
     SEDMI_REQUIRE(w->gru_w_ih && w->gru_w_hh && w->gru_b_ih && w->gru_b_hh && w->fc_w && w->fc_b, "null weight pointer");
     auto *m = new sedmi_basic_rcnn();

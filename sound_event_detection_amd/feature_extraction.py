@@ -142,15 +142,16 @@ def mel_statistics(mel: torch.Tensor):
 # ---------------------------------------------------------------------------
 
 def _load_wav(path: str, sr: int, offset: float, duration: float) -> np.ndarray:
-    """Mono float32 samples [offset, offset+duration) seconds of a WAV file at
-    its native rate, which must equal ``sr``.  The reference uses
-    librosa.load (feature_extraction.py:37), which also resamples; resampling
-    is not implemented here (librosa's soxr backend is not available), so a
-    file at another rate is rejected rather than silently mis-read."""
+    """Mono float32 samples [offset, offset+duration) seconds of a WAV file,
+    at rate ``sr``: the counterpart of librosa.load(path, sr=, offset=,
+    duration=) (feature_extraction.py:37), on the CPU like the reference's.
+    A file at another rate is resampled after slicing, as librosa does, with a
+    polyphase filter (scipy.signal.resample_poly); librosa's default resampler
+    (soxr_hq) is not available here, so resampled audio is close to but not
+    bit-identical with the reference's -- files at the dataset's own rate
+    (16 kHz DESED / BirdSED, 44.1 kHz TUT) are read exactly."""
     from scipy.io import wavfile
     native, data = wavfile.read(path, mmap=True)
-    if native != sr:
-        raise _lib.SedmiError(f"{path}: sample rate {native} != {sr}; resample offline or pass audio_loader=")
     a, b = int(round(offset * native)), int(round(offset * native)) + int(round(duration * native))
     data = np.asarray(data[a:b])
     if data.dtype.kind == "i":
@@ -160,6 +161,12 @@ def _load_wav(path: str, sr: int, offset: float, duration: float) -> np.ndarray:
     data = data.astype(np.float32)
     if data.ndim == 2:
         data = data.mean(axis=1)
+    if native != sr and len(data):
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(sr), int(native))
+        n_out = int(np.ceil(len(data) * sr / native))          # librosa.resample's output length
+        data = resample_poly(data.astype(np.float64), sr // g, native // g)[:n_out].astype(np.float32)
     return data
 
 

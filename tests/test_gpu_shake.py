@@ -224,3 +224,18 @@ def test_basic_rcnn_wide_input_odd_length_vs_oracle():
     got = m(x.cuda()).cpu().numpy()
     assert got.shape == want.shape == (2, 5, 6)
     np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
+def test_basic_rcnn_odd_width_is_floored_like_the_reference():
+    # frequency_dim 41: conv3 yields 33 columns, MaxPool2d(2, 2) keeps 16 (models.py:34,36: (F - 8) // 2)
+    from oracle import shake
+    from sound_event_detection_amd.models import BasicRCNN
+    sd = synth.synth_shake_state_dict(synth.basic_rcnn_state_dict_spec(5, 41), 7)
+    m = BasicRCNN(5, 41)
+    m.load_state_dict(sd)
+    m = m.eval().cuda()
+    x = torch.from_numpy(synth.synth_shake_feats(23, 3, 21, 41))
+    want = shake.basic_rcnn_forward(sd, x).numpy()
+    got = m(x.cuda()).cpu().numpy()
+    assert got.shape == want.shape == (3, 10, 5)
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
