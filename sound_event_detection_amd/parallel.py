@@ -14,6 +14,11 @@ has exactly two optional exchange steps:
 
 Both take whatever tensors the active backend supports, so the same code runs
 on gloo/CPU in the unit tests.
+
+``predict_files_sharded`` is the file-level prediction loop (training.py:333-365)
+over all ranks: whole recordings are dealt to ranks by their clip counts, every
+rank runs ``predict.predict_files`` on its share, and the event lists are
+gathered in file order (a few hundred bytes per event, once per call).
 """
 from __future__ import annotations
 
@@ -71,3 +76,31 @@ def all_reduce_mel_stats(s: torch.Tensor, s2: torch.Tensor, count: float, group=
     mean = buf[:m] / n
     var = (buf[m:2 * m] / n - mean * mean).clamp_min(0.0)
     return mean, var.sqrt()
+
+
+def predict_files_sharded(model, test_files, dataset_location, dataset, clip_length, *args, group=None,
+                          audio_duration=None, predict_fn=None, **kwargs):
+    """``predict.predict_files`` with the files split over the ranks of ``group``.
+
+    Same positional arguments as ``predict_files`` (after ``clip_length``: n_fft, n_mels, hop_length, win_length,
+    id2cls, block_length, ...).  Recordings stay whole (a recording's clips are decoded as one frame sequence,
+    training.py:350), ranks get contiguous runs of files balanced by clip count, and every rank returns the
+    complete event list in the order of ``test_files`` -- what the single-process call returns.
+    ``return_probs`` is not supported here (frame predictions stay on the rank that made them)."""
+    import numpy as np
+
+    from . import feature_extraction as fe
+    if kwargs.get("return_probs"):
+        raise ValueError("predict_files_sharded returns events only")
+    if predict_fn is None:
+        from .predict import predict_files as predict_fn
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    get_dur = audio_duration or fe._wav_duration
+    clip_s = 0.001 * clip_length
+    counts = [int(np.ceil(get_dur(dataset_location + dataset + '/' + f) / clip_s)) for f in test_files]
+    a, b, _, _ = shard_recordings(counts, rank, world)
+    mine = predict_fn(model, list(test_files[a:b]), dataset_location, dataset, clip_length, *args,
+                      audio_duration=audio_duration, **kwargs)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return [e for part in parts for e in part]

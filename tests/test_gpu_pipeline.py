@@ -68,7 +68,7 @@ def test_buffers_are_reused_for_smaller_batches_and_other_recording_tables():
         pipe.run(yd, clips_per_recording=[2, 3])
 
 
-def test_exchange_steps_over_rccl_on_device_tensors():
+def test_exchange_steps_over_rccl_on_device_tensors(tmp_path):
     """backend "nccl" is RCCL on ROCm.  One rank on the one GPU of the test box: initialises the communicator and
     runs both collectives of parallel.py on device tensors."""
     import torch.distributed as dist
@@ -95,5 +95,19 @@ def test_exchange_steps_over_rccl_on_device_tensors():
         work.wait()
         torch.cuda.synchronize(dev)
         assert torch.equal(out[0], local)
+        # the file-level loop over the ranks of the group (here: one) returns what the single-process call returns
+        from scipy.io import wavfile
+        from sound_event_detection_amd.predict import predict_files
+        d = os.path.join(str(tmp_path), "desed_2022")
+        os.makedirs(d)
+        names = []
+        for i, seconds in enumerate((12.5, 10.0, 3.0)):
+            y = np.concatenate([synth.synth_clip(50 + i), synth.synth_clip(60 + i)])[:int(seconds * SR)]
+            wavfile.write(os.path.join(d, f"f{i}.wav"), SR, np.round(y * 32767).astype(np.int16))
+            names.append(f"f{i}.wav")
+        id2cls = {i: f"c{i}" for i in range(10)}
+        m = _crnn(0)
+        args = (m, names, str(tmp_path) + "/", "desed_2022", 10000, N_FFT, 128, HOP, WIN, id2cls, 40)
+        assert parallel.predict_files_sharded(*args) == predict_files(*args)
     finally:
         dist.destroy_process_group()

@@ -56,3 +56,37 @@ def test_exchange_steps_on_two_gloo_ranks():
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, 7), nprocs=2, join=True)
+
+
+def _fake_predict(model, files, dataset_location, dataset, clip_length, *args, audio_duration=None, **kw):
+    # two events per file, named after it: enough to check order and completeness
+    return [(f, 0.0, 1.0, "a") for f in files] + [(f, 2.0, 3.0, "b") for f in files]
+
+
+def _sharded_worker(rank, world, port, files, durations):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = parallel.predict_files_sharded(None, files, "/data/", "desed_2022", 10000, 2048, 128, 320, 640, {}, 40,
+                                             audio_duration=lambda p: durations[p.rsplit("/", 1)[1]],
+                                             predict_fn=_fake_predict)
+        counts = [int(np.ceil(durations[f] / 10.0)) for f in files]
+        want = []
+        for r in range(world):
+            a, b, _, _ = parallel.shard_recordings(counts, r, world)
+            want += _fake_predict(None, files[a:b], None, None, None)
+        assert got == want
+        assert sorted({e[0] for e in got}) == sorted(files)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_file_level_prediction_sharded_over_two_gloo_ranks():
+    files = [f"f{i}.wav" for i in range(7)]
+    durations = {f: 10.0 * (1 + (3 * i) % 5) - 0.5 for i, f in enumerate(files)}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, files, durations), nprocs=2, join=True)
