@@ -1238,16 +1238,24 @@ constexpr int AT_D = 128, AT_KB = 32;
 constexpr int AT_KSB = AT_D * 2 + 16;      // bytes per key row of a K plane
 constexpr int AT_VSB = AT_KB * 2 + 16;     // bytes per dim row of a V^T plane
 
+// n_splits > 1: the keys are cut into n_splits ranges of whole 32-key blocks and blockIdx.x = query tile * n_splits +
+// range; a workgroup then leaves its normalised partial output in part_o [range][row][1024] and its running maximum
+// and sum in part_ml [range][row][head][2] for attention_merge_kernel (used when the grid would otherwise fill the
+// chip's workgroup slots badly: few long recordings).
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__restrict__ qkv,   // [clip*T + t][3*1024]
                                                               float *__restrict__ out,         // [clip*T + t][1024]
-                                                              int T, float scale) {
+                                                              int T, float scale, int n_splits, float *__restrict__ part_o,
+                                                              float *__restrict__ part_ml, long total_rows) {
     __shared__ __attribute__((aligned(16))) char kh[AT_KB * AT_KSB], kl[AT_KB * AT_KSB];
     __shared__ __attribute__((aligned(16))) char vth[AT_D * AT_VSB], vtl[AT_D * AT_VSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int head = blockIdx.y;
     const long row0 = static_cast<long>(blockIdx.z) * T;
-    const int q = blockIdx.x * 128 + wave * 32 + col32;
+    const int qtile = blockIdx.x / n_splits, split = blockIdx.x - qtile * n_splits;
+    const int q = qtile * 128 + wave * 32 + col32;
+    const int kb_per = ((T + AT_KB - 1) / AT_KB + n_splits - 1) / n_splits;          // key blocks per range
+    const int k_begin = split * kb_per * AT_KB, k_end = min(T, k_begin + kb_per * AT_KB);
     const float *base = qkv + row0 * 3072 + head * AT_D;
 
     // B operand of S^T: this lane's (scaled) query, dims 16 ks + 8 half + 0..7 of k-step ks
@@ -1303,8 +1311,8 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
                 for (int e = 0; e < 4; ++e) vreg[j][e][kk] = ok ? p[32 * e] : 0.f;
             }
     };
-    load_kv(0);
-    for (int kb0 = 0; kb0 < T; kb0 += AT_KB) {
+    load_kv(k_begin);
+    for (int kb0 = k_begin; kb0 < k_end; kb0 += AT_KB) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1331,7 +1339,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
             }
         }
         __syncthreads();
-        if (kb0 + AT_KB < T) load_kv(kb0 + AT_KB);
+        if (kb0 + AT_KB < k_end) load_kv(kb0 + AT_KB);
         // S^T[key][query]: A row = key col32, B column = query col32
         f32x16 sc;
 #pragma unroll
@@ -1393,8 +1401,16 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
             }
     }
     if (q < T) {
-        const float inv = 1.0f / l;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;          // l == 0: an empty key range (its weight in the merge is 0)
         float *op = out + (row0 + q) * 1024 + head * AT_D;
+        if (n_splits > 1) {
+            op = part_o + (static_cast<long>(split) * total_rows + row0 + q) * 1024 + head * AT_D;
+            if (half == 0) {
+                float *ml = part_ml + ((static_cast<long>(split) * total_rows + row0 + q) * 8 + head) * 2;
+                ml[0] = m;
+                ml[1] = l;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -1402,6 +1418,29 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
                 *reinterpret_cast<float4 *>(op + 32 * nt + 8 * r4 + 4 * half) =
                     make_float4(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv, o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv);
     }
+}
+
+// Combines the partial outputs of n_splits key ranges: out = sum_s w_s o_s / sum_s w_s with w_s = l_s exp(m_s - max m).
+// One thread per (row, head, 4 dims).
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                              float *__restrict__ out, long total_rows, int n_splits) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total_rows * 256) return;
+    const long row = i >> 8;
+    const int d4 = static_cast<int>(i & 255) * 4, head = d4 >> 7;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < n_splits; ++sp) mx = fmaxf(mx, part_ml[((sp * total_rows + row) * 8 + head) * 2]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wsum = 0.f;
+    for (int sp = 0; sp < n_splits; ++sp) {
+        const float *ml = part_ml + ((sp * total_rows + row) * 8 + head) * 2;
+        const float w = ml[1] > 0.f ? ml[1] * __expf(ml[0] - mx) : 0.f;
+        const float4 o = *reinterpret_cast<const float4 *>(part_o + (sp * total_rows + row) * 1024 + d4);
+        acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y); acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
+        wsum += w;
+    }
+    const float inv = 1.0f / wsum;
+    *reinterpret_cast<float4 *>(out + row * 1024 + d4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 // out = LayerNorm(x + y) over rows of 1024 (post-LN residual), one wave per row; out may alias x
@@ -1605,7 +1644,7 @@ struct sedmi_shake_rcnn {
 };
 
 struct sedmi_shake_transformer {
-    int n_class = 0, n_layers = 0;
+    int n_class = 0, n_layers = 0, num_cus = 0;
     ShakeCnnDev cnn;
     LinearDev fc1;
     EncoderLayerDev layers[kMaxEncoderLayers];
@@ -1630,12 +1669,30 @@ struct ShakeScratch {
     unsigned *sync_words;                    // and its status word + flags
     size_t sync_bytes;
     float *x, *qkv, *att, *ff;               // ShakeTransformer
+    float *part_o, *part_ml;                 // attention over several key ranges: partial outputs, (max, sum)
+    int att_splits;
     size_t bytes;
 };
 
 enum { SHAKE_CNN_ONLY = 0, SHAKE_RCNN = 1, SHAKE_TRANSFORMER = 2 };
 
-ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
+// Key ranges for the attention kernel.  Its grid is n * 8 heads * ceil(T / 128) equal workgroups on 2 * num_cus
+// slots; when that is a small non-integer number of rounds (2 recordings x 6000 tokens: 752 workgroups on 512
+// slots = 1.47 -> 2 rounds) cutting the keys into S ranges gives S times as many workgroups of 1/S the length:
+// ceil(1.47 S) / S rounds.  Ranges keep at least 512 keys; S is only raised for a gain of 10 % or more.
+int attention_splits(long n, long T4, int num_cus) {
+    if (num_cus <= 0 || T4 < 1024) return 1;
+    const double tiles = static_cast<double>(n) * 8 * sedmi::ceil_div(T4, 128), slots = 2.0 * num_cus;
+    int best = 1;
+    double best_t = std::ceil(tiles / slots);
+    for (int S = 2; S <= 4 && T4 / S >= 512; ++S) {
+        const double t = std::ceil(tiles * S / slots) / S;
+        if (t < 0.9 * best_t) { best = S; best_t = t; }
+    }
+    return best;
+}
+
+ShakeScratch carve_shake(void *ws, long n, long T, int kind, int num_cus = 0) {
     ShakeScratch sc{};
     size_t off = 0;
     auto take = [&](size_t n_floats) {
@@ -1666,6 +1723,11 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind) {
         sc.qkv = take(static_cast<size_t>(n) * T4 * 3072);
         sc.att = take(static_cast<size_t>(n) * T4 * 1024);
         sc.ff = take(static_cast<size_t>(n) * T4 * 2048);
+        sc.att_splits = attention_splits(n, T4, num_cus);
+        if (sc.att_splits > 1) {
+            sc.part_o = take(static_cast<size_t>(sc.att_splits) * n * T4 * 1024);
+            sc.part_ml = take(static_cast<size_t>(sc.att_splits) * n * T4 * 16);
+        }
     }
     sc.bytes = off;
     return sc;
@@ -1838,9 +1900,16 @@ int run_encoder(const sedmi_shake_transformer *m, long n, int T4, const ShakeScr
         {
             sedmi::ProfileScope prof("shake_tf_attention", s, 4.0 * n * 8 * static_cast<double>(T4) * T4 * AT_D,
                                      4.0 * rows * 4096.0);
-            hipLaunchKernelGGL(attention_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128)), 8, static_cast<unsigned>(n)),
-                               dim3(256), 0, s, sc.qkv, sc.att, T4, 1.0f / std::sqrt(static_cast<float>(AT_D)));
+            const int S = sc.att_splits > 1 ? sc.att_splits : 1;
+            hipLaunchKernelGGL(attention_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128) * S), 8, static_cast<unsigned>(n)),
+                               dim3(256), 0, s, sc.qkv, sc.att, T4, 1.0f / std::sqrt(static_cast<float>(AT_D)), S, sc.part_o,
+                               sc.part_ml, rows);
             SEDMI_CHECK_LAUNCH();
+            if (S > 1) {
+                hipLaunchKernelGGL(attention_merge_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows * 256, 256))), dim3(256), 0,
+                                   s, sc.part_o, sc.part_ml, sc.att, rows, S);
+                SEDMI_CHECK_LAUNCH();
+            }
         }
         if ((rc = launch_linear("shake_tf_out_proj", L.out_proj, sc.att, sc.ff, rows, false, s))) return rc;
         {
@@ -2124,6 +2193,12 @@ int sedmi_shake_transformer_create(sedmi_shake_transformer **out, const sedmi_sh
     auto *m = new sedmi_shake_transformer();
     m->n_class = w->n_class;
     m->n_layers = w->n_layers;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&m->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            m->num_cus = 0;
+    }
     auto fail = [&](int code) { sedmi_shake_transformer_destroy(m); return code; };
     auto ident = [](int k) { return k; };
     if ((rc = create_shake_cnn(m->cnn, w->cnn))) return fail(rc);
@@ -2161,7 +2236,7 @@ int sedmi_shake_transformer_destroy(sedmi_shake_transformer *m) {
 
 size_t sedmi_shake_transformer_workspace_bytes(const sedmi_shake_transformer *m, int64_t n_clips, int64_t T) {
     if (!m || n_clips <= 0 || T < 4) return 0;
-    return carve_shake(nullptr, n_clips, T, SHAKE_TRANSFORMER).bytes;
+    return carve_shake(nullptr, n_clips, T, SHAKE_TRANSFORMER, m->num_cus).bytes;
 }
 
 int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const float *feats, int64_t n, int64_t T,
@@ -2171,7 +2246,7 @@ int sedmi_shake_transformer_forward_f32(const sedmi_shake_transformer *m, const 
     if (n == 0 || T < 4) return SEDMI_OK;
     SEDMI_REQUIRE(feats && alphas && logits && ws, "null pointer");
     SEDMI_REQUIRE(n <= 65535, "at most 65535 clips per call");
-    ShakeScratch sc = carve_shake(ws, n, T, SHAKE_TRANSFORMER);
+    ShakeScratch sc = carve_shake(ws, n, T, SHAKE_TRANSFORMER, m->num_cus);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T4 = static_cast<int>(T / 4);
