@@ -220,7 +220,12 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     // mel-major row (single 4-byte writes cost 4-5x the output bytes in HBM write traffic).
     constexpr int FB = 32, ROUNDS = FB / WAVES;
     static_assert(ROUNDS % 4 == 0, "frames per wave and block must be a multiple of 4");
-    float keep[2][4];              // [filter pass][frame of the group of four]; later passes write directly
+    // A lane collects its two filters' values over the wave's KEEP consecutive frames and writes them as KEEP / 4
+    // adjacent 16-byte pieces issued back to back (32 contiguous bytes of a mel-major row): PMC WRITE_SIZE per output
+    // byte is 4.7x for single 4-byte writes, 2.6-3.0x for lone 16-byte pieces.
+    constexpr int KEEP = 8;
+    static_assert(ROUNDS % KEEP == 0, "a wave's frames of a block are whole groups");
+    float keep[2][KEEP];           // [filter of the pair][frame of the group]; later chunks of filters write directly
     const unsigned blocks_per_clip = a.tiles_per_clip, total_blocks = static_cast<unsigned>(a.total_tiles);
     // block -> (clip, first frame of this wave in it); one 32-bit division per block, not per frame
     auto block_pos = [&](unsigned blk, unsigned &clip, int &tb) {
@@ -425,9 +430,9 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
                 if (has_b) acc_b = (acc_b - a.mean[m_b]) * a.istd[m_b];
             }
             if (chunk == 0) {
-                const int j4 = t & 3;
+                const int j4 = t & (KEEP - 1);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
+                for (int jj = 0; jj < KEEP; ++jj)
                     if (jj == j4) {
                         keep[0][jj] = acc_a;
                         keep[1][jj] = acc_b;
@@ -437,8 +442,8 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
                 if (has_b) a.out[(clip * a.n_mels + m_b) * static_cast<long>(a.T) + t] = acc_b;
             }
         }
-        if ((t & 3) == 3 || t + 1 >= a.T) {            // last frame of its group of four (or of the clip)
-            const int t0 = t & ~3, nl = t - t0 + 1;
+        if ((t & (KEEP - 1)) == KEEP - 1 || t + 1 >= a.T) {   // last frame of its group (or of the clip)
+            const int t0 = t & ~(KEEP - 1), nl = t - t0 + 1;
             const int C = a.n_mels < 128 ? a.n_mels : 128;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -446,12 +451,16 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
                 const bool has = pass == 0 ? lane < (C + 1) / 2 : lane < C / 2;
                 if (has) {
                     float *dst = a.out + (clip * a.n_mels + m) * static_cast<long>(a.T) + t0;
-                    if (nl == 4) {                     // rows are T floats apart: 4-byte aligned only
-                        *reinterpret_cast<Float4U *>(dst) = Float4U{keep[pass][0], keep[pass][1], keep[pass][2], keep[pass][3]};
-                    } else {
 #pragma unroll
-                        for (int jj = 0; jj < 3; ++jj)
-                            if (jj < nl) dst[jj] = keep[pass][jj];
+                    for (int q4 = 0; q4 < KEEP / 4; ++q4) {
+                        if (nl >= 4 * q4 + 4) {        // rows are T floats apart: 4-byte aligned only
+                            *reinterpret_cast<Float4U *>(dst + 4 * q4) =
+                                Float4U{keep[pass][4 * q4], keep[pass][4 * q4 + 1], keep[pass][4 * q4 + 2], keep[pass][4 * q4 + 3]};
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < 3; ++jj)
+                                if (4 * q4 + jj < nl) dst[4 * q4 + jj] = keep[pass][4 * q4 + jj];
+                        }
                     }
                 }
             }
