@@ -404,8 +404,14 @@ def main():
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 rec = json.load(f).get(dom["name"])
             if rec:
-                roof["traffic"] = rec["hbm_bytes_per_launch"]          # bytes per launch, PMC-measured
+                # PMC-measured bytes per launch, scaled from the clips a launch covered in the profiled run to the
+                # clips a launch covers here (every one of these kernels moves bytes in proportion to its clips)
+                here = clips * steps / max(dom["launches"], 1)
+                scale = here / rec.get("clips_per_launch", here)
+                roof["traffic"] = rec["hbm_bytes_per_launch"] * scale
+                roof["clips_per_launch"] = here
                 roof["traffic_detail"] = {k: rec[k] for k in ("fetch_size_kib_raw", "write_size_kib", "note")}
+                roof["traffic_detail"]["scaled_by"] = scale
                 roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
         except (OSError, ValueError, KeyError):
             pass

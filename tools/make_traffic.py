@@ -23,7 +23,8 @@ def bench_name(k):
     m = re.match(r"linear_split_kernel<768, (\d+),", k)
     if m:
         return "gru_input_proj_split<%s>" % m.group(1)
-    for a, b in (("mel_kernel", "mel_kernel"), ("conv0_kernel", "conv0_kernel"), ("gru_split_kernel", "gru_kernel"),
+    for a, b in (("mel_kernel", "mel_kernel"), ("conv0_kernel", "conv0_kernel"), ("conv0_split_kernel", "conv0_kernel"),
+                 ("clip_scale_kernel", "clip_scale_kernel"), ("gru_split_kernel", "gru_kernel"),
                  ("gru_kernel", "gru_kernel"), ("head_small_kernel", "head_kernel"), ("head_kernel", "head_kernel")):
         if k.startswith(a):
             return b
@@ -49,7 +50,8 @@ def main():
             "per launch, as in the default run; mel/GRU/head launches cover 1024 clips here, 4096 in the default run); "
             "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request; calibrated on a torch add in the same pass)")
     out = {k: dict(hbm_bytes_per_launch=1024.0 * (2.0 * fetch[k] + write.get(k, 0.0)), fetch_size_kib_raw=fetch[k],
-                   write_size_kib=write.get(k, 0.0), note=note) for k in fetch}
+                   write_size_kib=write.get(k, 0.0), clips_per_launch=512 if k.startswith(("conv", "clip_scale")) else 1024, note=note)
+           for k in fetch}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         print(f"{k:32s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")

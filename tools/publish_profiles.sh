@@ -19,7 +19,8 @@ import json, sys
 d = json.load(open(sys.argv[1])); t = json.load(open("profiles/traffic.json"))
 rec = t.get(d["roofline"]["kernel"])
 if rec:
-    d["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+    here = d["roofline"].get("clips_per_launch") or rec.get("clips_per_launch")
+    d["roofline"]["traffic"] = rec["hbm_bytes_per_launch"] * here / rec.get("clips_per_launch", here)
     d["roofline"]["traffic_detail"] = {k: rec[k] for k in ("fetch_size_kib_raw", "write_size_kib", "note")}
 json.dump(d, open(sys.argv[2], "w"))
 PY
