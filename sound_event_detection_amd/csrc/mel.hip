@@ -147,6 +147,12 @@ struct MelGeom {
     static constexpr int SCR_B = 16 * STRIDE_B;
     static constexpr int SCR = (SCR_A > SCR_B ? (SCR_A > NC ? SCR_A : NC) : (SCR_B > NC ? SCR_B : NC));
     static constexpr int NPAIR = R1 / 2 + 1;           // bins lane + 64*j <= NC/2
+    // column of element (lane group g, radix-4 output r, i = k1 % IB) in a row of transpose B (4 R1 columns):
+    // bits from the bottom: i, the low bits of r that fill up to three bits, g >> 1, g & 1, the rest of r
+    static constexpr int IB = R1 / 4, RL = 8 / IB;
+    __device__ static constexpr int col_b(int g, int r, int i) {
+        return i + IB * (r % RL) + 8 * (g >> 1) + 16 * (g & 1) + 32 * (r / RL);
+    }
 };
 
 // ROW0 / NROW: the first-stage rows n1 in [ROW0, ROW0 + NROW) are the only ones whose 64 complex
@@ -306,14 +312,18 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
         wave_lds_fence();                              // all reads before scratch is reused
 #pragma unroll
         for (int i = 0; i < R1 / 4; ++i) {
-            const int k1 = g * (R1 / 4) + i;
             dif<4>(br[i], bi[i]);
+            // twiddle W_64^(q r), transpose B: row q, column col_b(g, r, i) (k1 = g * (R1 / 4) + i).  The column
+            // bits are arranged so that neither side of the transpose meets a bank conflict: bit 4 is the low
+            // bit of the lane group g, so the 32 lanes that store together here (16 q x 2 g, 65 q + 16 g complex
+            // apart) fall into 32 different bank pairs, and bits 0-4 are exactly the bits of the output position
+            // k1 + R1 r (mod 32) that the lanes of stage 2b store to.
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {              // twiddle W_64^(q r), transpose B: [q][r*R1 + k1]
+            for (int p = 0; p < 4; ++p) {
                 const int r = bitrev<4>(p);
                 const float xr = br[i][p] * t2r[p] - bi[i][p] * t2i[p];
                 const float xi = br[i][p] * t2i[p] + bi[i][p] * t2r[p];
-                scr[q * G::STRIDE_B + r * R1 + k1] = make_float2(xr, xi);
+                scr[q * G::STRIDE_B + G::col_b(g, r, i)] = make_float2(xr, xi);
             }
         }
         wave_lds_fence();
@@ -338,7 +348,9 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             const int idx = lane + 64 * u;
             if (idx < 4 * R1) {
                 dif<16>(cr[u], ci[u]);
-                const int r = idx / R1, k1 = idx % R1;
+                // inverse of col_b: which (r, k1) column idx of transpose B holds
+                const int r = (idx >> 5) * G::RL + (idx / G::IB) % G::RL;
+                const int k1 = (2 * ((idx >> 3) & 1) + ((idx >> 4) & 1)) * G::IB + idx % G::IB;
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {         // natural order Z[k], k = k1 + R1 (r + 4 s)
                     const int s = bitrev<16>(p);

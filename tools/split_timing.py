@@ -17,8 +17,8 @@ SECTIONS = ["prologue", "chunk sync", "stage+sync", "main loop", "bn", "phase sy
 
 def main():
     dev = torch.device("cuda", 0)
-    model, _ = bench.make_model(dev)
-    pipe = SedPipeline(model, sr=bench.SR, n_fft=bench.N_FFT, n_mels=bench.N_MELS, hop_length=bench.HOP,
+    model, _ = bench.make_crnn(dev)
+    pipe = SedPipeline(model, sr=bench.SR, n_fft=bench.N_FFT, n_mels=128, hop_length=bench.HOP,
                        win_length=bench.WIN)
     y = bench.make_clips(512, 0, dev)
     h = C.CDLL(_lib.LIB_PATH)
