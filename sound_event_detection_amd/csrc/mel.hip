@@ -418,8 +418,11 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
                 const bool in_a = i < len_a;
                 const float4 wa = *reinterpret_cast<const float4 *>(melw + ptr + i);
                 const float4 wb = *reinterpret_cast<const float4 *>(melw + ptr + i + 4);
+                // run starts are multiples of four bins (the host pads the front of a run with zero weights), so
+                // the eight bins come as two 16-byte reads
                 const float *pp = pw + (in_a ? start_a : base_b) + i;
-                const float p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4], p5 = pp[5], p6 = pp[6], p7 = pp[7];
+                const float4 pa4 = *reinterpret_cast<const float4 *>(pp), pb4 = *reinterpret_cast<const float4 *>(pp + 4);
+                const float p0 = pa4.x, p1 = pa4.y, p2 = pa4.z, p3 = pa4.w, p4 = pb4.x, p5 = pb4.y, p6 = pb4.z, p7 = pb4.w;
                 float s0 = wa.x * p0, s1 = wa.y * p1;
                 s0 = fmaf(wa.z, p2, s0); s1 = fmaf(wa.w, p3, s1);
                 s0 = fmaf(wb.x, p4, s0); s1 = fmaf(wb.y, p5, s1);
@@ -629,7 +632,10 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
         const int first = 128 * (mp / 64), C = std::min(128, n_mels - first), l = mp % 64;
         const int fa = l < (C + 1) / 2 ? first + l : -1;
         const int fb = l < C / 2 ? first + C - 1 - l : -1;
-        const int la = fa >= 0 ? (len[fa] + 7) & ~7 : 0, lb = fb >= 0 ? (len[fb] + 7) & ~7 : 0;
+        // a run starts at the multiple of four bins at or below the filter's first bin (16-byte reads of the
+        // power spectrum) and is zero-padded at both ends to a multiple of eight bins
+        const int sa = fa >= 0 ? start[fa] & ~3 : 0, sb = fb >= 0 ? start[fb] & ~3 : 0;
+        const int la = fa >= 0 ? (len[fa] + start[fa] - sa + 7) & ~7 : 0, lb = fb >= 0 ? (len[fb] + start[fb] - sb + 7) & ~7 : 0;
         // the 16-byte weight reads that 16 neighbouring lanes issue together should fall into 16 different groups
         // of four LDS banks: start each run at the first multiple of four floats whose bank group no other pair of
         // its 16-group uses yet
@@ -638,13 +644,14 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
         while (used_groups >> ((wsp.size() / 4) % 16) & 1u) wsp.insert(wsp.end(), 4, 0.f);
         used_groups |= 1u << ((wsp.size() / 4) % 16);
         const int ptr = static_cast<int>(wsp.size());
+        // (bins outside [start, start + len) of the filter's dense row are zero)
         for (int k = 0; k < la; ++k)
-            wsp.push_back(k < len[fa] ? p->fb_dense[static_cast<size_t>(fa) * nb + start[fa] + k] : 0.f);
+            wsp.push_back(sa + k < nb ? p->fb_dense[static_cast<size_t>(fa) * nb + sa + k] : 0.f);
         for (int k = 0; k < lb; ++k)
-            wsp.push_back(k < len[fb] ? p->fb_dense[static_cast<size_t>(fb) * nb + start[fb] + k] : 0.f);
-        meta[5 * mp + 0] = fa >= 0 ? start[fa] : 0;
+            wsp.push_back(sb + k < nb ? p->fb_dense[static_cast<size_t>(fb) * nb + sb + k] : 0.f);
+        meta[5 * mp + 0] = sa;
         meta[5 * mp + 1] = la;
-        meta[5 * mp + 2] = (fb >= 0 ? start[fb] : 0) - la;
+        meta[5 * mp + 2] = sb - la;
         meta[5 * mp + 3] = la + lb;
         meta[5 * mp + 4] = ptr;
     }
