@@ -132,6 +132,16 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One complex value from LDS as a single ds_read_b64.  Two neighbouring 8-byte reads would otherwise be fused into
+// ds_read2_b64, which occupies the LDS array for 8 cycles per wave where two ds_read_b64 take 2 each; a volatile
+// access is never fused.
+__device__ __forceinline__ float2 lds_read_c(const float2 *p) {
+    // (the LDS address space is spelled out: address-space inference leaves volatile accesses as flat ones)
+    typedef const volatile unsigned long long __attribute__((address_space(3))) *lds_u64;
+    const unsigned long long raw = *(lds_u64)(p);
+    return __builtin_bit_cast(float2, raw);
+}
+
 // four floats stored as one 16-byte access that is only 4-byte aligned (dword alignment is all a
 // multi-dword global access needs)
 typedef float Float4U __attribute__((ext_vector_type(4), aligned(4)));
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             const int k1 = g * (R1 / 4) + i;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float2 v = scr[k1 * G::STRIDE_A + 16 * p + q];
+                const float2 v = lds_read_c(&scr[k1 * G::STRIDE_A + 16 * p + q]);
                 br[i][p] = v.x;
                 bi[i][p] = v.y;
             }
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             if (idx < 4 * R1) {
 #pragma unroll
                 for (int qq = 0; qq < 16; ++qq) {
-                    const float2 v = scr[qq * G::STRIDE_B + idx];
+                    const float2 v = lds_read_c(&scr[qq * G::STRIDE_B + idx]);
                     cr[u][qq] = v.x;
                     ci[u][qq] = v.y;
                 }
@@ -373,8 +383,8 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
             const int k = lane + 64 * j;
             pa[j] = pb[j] = 0.f;
             if (k <= NC / 2) {
-                const float2 za = scr[k];
-                const float2 zb = scr[(NC - k) & (NC - 1)];
+                const float2 za = lds_read_c(&scr[k]);
+                const float2 zb = lds_read_c(&scr[(NC - k) & (NC - 1)]);
                 const float er = 0.5f * (za.x + zb.x), ei = 0.5f * (za.y - zb.y);
                 const float oR = 0.5f * (za.y + zb.y), oI = -0.5f * (za.x - zb.x);
                 float wr, wi;
