@@ -222,17 +222,18 @@ static int decode_check(const float *p, int64_t total_frames, int n_class, const
     return SEDMI_OK;
 }
 
-// count pass -> exclusive scan -> write pass; `scratch` holds the per-(recording, class) counters
+// count pass -> exclusive scan -> write pass; `work` (device memory: the caller's workspace or the looked-up
+// address of the static array, never the array's name) holds the per-(recording, class) counters
 // (int) followed, 256-byte aligned, by their scanned offsets (int64).  `timed` = bracket the launches
 // with profiling events when profiling is on (creating events allocates, so the allocation-free entry
 // point passes false).
 static int decode_launch(const float *p, int64_t total_frames, int n_class, const int64_t *seg_start,
                          const int64_t *seg_cutoff, int64_t n_seg, float thr, int apply_sigmoid, int median_win,
                          int32_t *ev_seg, int32_t *ev_cls, int32_t *ev_on, int32_t *ev_off, int64_t capacity,
-                         int64_t *n_events, void *scratch, bool timed, hipStream_t s) {
+                         int64_t *n_events, void *work, bool timed, hipStream_t s) {
     const long pairs = static_cast<long>(n_seg) * n_class;
-    int *counts = static_cast<int *>(scratch);
-    long long *offsets = reinterpret_cast<long long *>(static_cast<char *>(scratch) +
+    int *counts = static_cast<int *>(work);
+    long long *offsets = reinterpret_cast<long long *>(static_cast<char *>(work) +
                                                        sedmi::align_up(pairs * sizeof(int), 256));
     const unsigned grid = static_cast<unsigned>(sedmi::ceil_div(pairs, kWavesPerBlock));
     const int half = median_win / 2;
