@@ -685,11 +685,16 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     };
     // one 16-clip tile at a time: chain, then gates (the next tile's chain of this wave and the other wave's
     // work cover the latency of the gate arithmetic's tail)
+    // gi of step s + 1 is requested before the work of step s and taken over after its barrier
+    if (T <= 0) return;
+    float g[2][3][4], gn[2][3][4];
+    load_gi(0, 0, g[0]);
+    load_gi(1, 0, g[1]);
 #pragma unroll 1
     for (int s = 0; s < T; ++s) {
-        float g[2][3][4];
-        load_gi(0, s, g[0]);
-        load_gi(1, s, g[1]);
+        const int sn = s + 1 < T ? s + 1 : s;
+        load_gi(0, sn, gn[0]);
+        load_gi(1, sn, gn[1]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4v acc[3];
@@ -697,6 +702,12 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
             gates(mt, s, acc, g[mt]);
         }
         __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[mt][q][i] = gn[mt][q][i];
     }
 }
 
