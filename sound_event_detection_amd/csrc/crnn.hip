@@ -711,6 +711,182 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     }
 }
 
+// Layer 0 of the GRU with its input projection inside the recurrence: gi = x . W_ih^T is formed per step from the
+// conv stack's output instead of being written to memory by a GEMM and read back (3.1 GB each way per 4096 clips,
+// which is what bounded the separate kernels).  Same wave layout as gru_split_kernel; per wave W_hh (hi, lo) and
+// the hi halves of W_ih live in registers (144 VGPRs) together with the lo half of W_ih's n gate (16); the lo halves
+// of its r and z gates (64 KB for one direction) sit in LDS beside the h planes and the x planes (the step's input
+// rows as f16 hi/lo, staged one step ahead by all threads: 32 clips x 128 values = 8 per thread).  The products
+// with x and with h keep separate accumulators because the two weight matrices carry different power-of-two scales.
+constexpr int GRU0_WLO_BYTES = (GRU_H / 32) * 2 * GRU_H * 64;            // [k-step of 32][gate r, z][unit][32 k] f16
+constexpr int GRU0_PLANES_BYTES = 2 * 2 * GRU_NB * GRU_PSB;              // [buffer][plane][clip row]
+constexpr int GRU0_LDS_BYTES = 2 * GRU0_PLANES_BYTES + GRU0_WLO_BYTES;   // h planes, x planes, W_ih lo (r, z)
+
+__global__ __launch_bounds__(512, 1) void gru0_fused_kernel(
+    const float *__restrict__ x,       // [clip][T][H]: the conv stack's output
+    const uint4 *__restrict__ wih,     // packed split [H/16][2 planes][6H][16] f16 (columns [dir][gate][unit]), times 2^Si
+    float wih_oscale,                  // 2^-Si
+    const float *__restrict__ bi,      // [2][3H]: b_ih (+ b_hh for r, z)
+    const uint4 *__restrict__ whh,     // packed split [2][H/16][2 planes][3H][16] f16, times 2^Sh
+    float whh_oscale,                  // 2^-Sh
+    const float *__restrict__ bhn,     // [2][H]
+    float *__restrict__ out,           // [clip][T][2H]
+    long n_clips, int T) {
+    extern __shared__ __attribute__((aligned(16))) char g0_lds[];
+    char *hpl = g0_lds, *xpl = g0_lds + GRU0_PLANES_BYTES, *wlo = g0_lds + 2 * GRU0_PLANES_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int dir = blockIdx.y;
+    const long b0 = static_cast<long>(blockIdx.x) * GRU_NB;
+    const int j = 16 * wave + n16;                    // hidden unit owned by this lane
+    if (T <= 0) return;
+
+    // B fragments of k-step ks (32 indices): this lane's 8 indices 32 ks + 8 kg .. + 7 of column (gate, j)
+    f16x8 wh[3][GRU_H / 32], wl[3][GRU_H / 32], vh[3][GRU_H / 32], vln[GRU_H / 32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            const int ks16 = 2 * ks + (kg >> 1);
+            const uint4 *p = whh + ((static_cast<long>(dir) * (GRU_H / 16) + ks16) * 2 * (3 * GRU_H) + g * GRU_H + j) * 2 + (kg & 1);
+            wh[g][ks] = __builtin_bit_cast(f16x8, p[0]);
+            wl[g][ks] = __builtin_bit_cast(f16x8, p[2 * 3 * GRU_H]);
+            const uint4 *q = wih + (static_cast<long>(ks16) * 2 * (6 * GRU_H) + dir * 3 * GRU_H + g * GRU_H + j) * 2 + (kg & 1);
+            vh[g][ks] = __builtin_bit_cast(f16x8, q[0]);
+            if (g == 2) vln[ks] = __builtin_bit_cast(f16x8, q[2 * 6 * GRU_H]);
+        }
+    // lo halves of W_ih's r and z columns of this direction into LDS, in the order the waves read them back:
+    // 16-byte piece number ((ks * 2 + g) * H + unit) * 4 + kg
+    for (int i = tid; i < GRU0_WLO_BYTES / 16; i += 512) {
+        const int kq = i & 3, unit = (i >> 2) % GRU_H, g = (i >> 2) / GRU_H % 2, ks = (i >> 2) / (2 * GRU_H);
+        const int ks16 = 2 * ks + (kq >> 1);
+        reinterpret_cast<uint4 *>(wlo)[i] =
+            wih[((static_cast<long>(ks16) * 2 + 1) * (6 * GRU_H) + dir * 3 * GRU_H + g * GRU_H + unit) * 2 + (kq & 1)];
+    }
+    const float b_r = bi[dir * 3 * GRU_H + j], b_z = bi[dir * 3 * GRU_H + GRU_H + j], b_in = bi[dir * 3 * GRU_H + 2 * GRU_H + j];
+    const float b_hn = bhn[dir * GRU_H + j];
+    for (int i = tid; i < 2 * GRU0_PLANES_BYTES / 4; i += 512) reinterpret_cast<unsigned *>(g0_lds)[i] = 0u;
+
+    // accumulator register i of tile mt is clip 16 mt + 4 kg + i
+    float hprev[2][4];
+    float *outp[2][4];
+    bool live[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hprev[mt][i] = 0.f;
+            const long b = b0 + 16 * mt + 4 * kg + i;
+            live[mt][i] = b < n_clips;
+            const long bc = live[mt][i] ? b : n_clips - 1;
+            outp[mt][i] = out + bc * T * (2 * GRU_H) + dir * GRU_H + j;
+        }
+    // staging: thread -> clip tid / 16, eight consecutive inputs starting at 8 (tid % 16)
+    const int sc = tid >> 4, sf = (tid & 15) * 8;
+    const long sclip = b0 + sc < n_clips ? b0 + sc : n_clips - 1;
+    const float *xrow = x + sclip * T * GRU_H + sf;
+    f32x4v xa, xb;
+    auto load_x = [&](int s) {
+        const long t = dir ? T - 1 - s : s;
+        xa = *reinterpret_cast<const f32x4v *>(xrow + t * GRU_H);
+        xb = *reinterpret_cast<const f32x4v *>(xrow + t * GRU_H + 4);
+    };
+    auto store_x = [&](int buf) {
+        uint4 hi, lo;
+        split2_f16(xa[0], xa[1], hi.x, lo.x);
+        split2_f16(xa[2], xa[3], hi.y, lo.y);
+        split2_f16(xb[0], xb[1], hi.z, lo.z);
+        split2_f16(xb[2], xb[3], hi.w, lo.w);
+        char *base = xpl + buf * 2 * GRU_NB * GRU_PSB + sc * GRU_PSB + sf * 2;
+        *reinterpret_cast<uint4 *>(base) = hi;
+        *reinterpret_cast<uint4 *>(base + GRU_NB * GRU_PSB) = lo;
+    };
+    load_x(0);
+    __syncthreads();                                   // planes zeroed, W_ih lo in place
+    store_x(0);
+    load_x(T > 1 ? 1 : 0);
+    __syncthreads();
+
+    // planes of step s: x in buffer s & 1 (written during step s - 1), h_{s-1} in buffer (s - 1) & 1
+    auto chain = [&](int mt, int s, f32x4v (&ax)[3], f32x4v (&ah)[3]) {
+        const int row = (16 * mt + n16) * GRU_PSB + 16 * kg;
+        const char *xh = xpl + (s & 1) * 2 * GRU_NB * GRU_PSB + row, *xl = xh + GRU_NB * GRU_PSB;
+        const char *hh = hpl + ((s & 1) ^ 1) * 2 * GRU_NB * GRU_PSB + row, *hl = hh + GRU_NB * GRU_PSB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            ax[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            ah[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+        f16x8 fxh[GRU_H / 32], fxl[GRU_H / 32];
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            fxh[ks] = *reinterpret_cast<const f16x8 *>(xh + ks * 64);
+            fxl[ks] = *reinterpret_cast<const f16x8 *>(xl + ks * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            f16x8 vl[3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                vl[q] = *reinterpret_cast<const f16x8 *>(wlo + (((ks * 2 + q) * GRU_H + j) * 4 + kg) * 16);
+            vl[2] = vln[ks];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ax[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fxl[ks], vh[q][ks], ax[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ax[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fxh[ks], vl[q], ax[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ax[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fxh[ks], vh[q][ks], ax[q], 0, 0, 0);
+        }
+        f16x8 fhh[GRU_H / 32], fhl[GRU_H / 32];
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            fhh[ks] = *reinterpret_cast<const f16x8 *>(hh + ks * 64);
+            fhl[ks] = *reinterpret_cast<const f16x8 *>(hl + ks * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ah[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fhl[ks], wh[q][ks], ah[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ah[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fhh[ks], wl[q][ks], ah[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ah[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fhh[ks], wh[q][ks], ah[q], 0, 0, 0);
+        }
+    };
+    auto gates = [&](int mt, int s, const f32x4v (&ax)[3], const f32x4v (&ah)[3]) {
+        const long t = dir ? T - 1 - s : s;
+        char *nh = hpl + (s & 1) * 2 * GRU_NB * GRU_PSB, *nl = nh + GRU_NB * GRU_PSB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float rg = sigmoidf_fast(fmaf(ah[0][i], whh_oscale, fmaf(ax[0][i], wih_oscale, b_r)));
+            const float zg = sigmoidf_fast(fmaf(ah[1][i], whh_oscale, fmaf(ax[1][i], wih_oscale, b_z)));
+            const float ng = tanhf_fast(fmaf(rg, fmaf(ah[2][i], whh_oscale, b_hn), fmaf(ax[2][i], wih_oscale, b_in)));
+            const float hn = fmaf(zg, hprev[mt][i] - ng, ng);      // (1 - z) * n + z * h
+            hprev[mt][i] = hn;
+            const int row = 16 * mt + 4 * kg + i;
+            _Float16 hi, lo;
+            split_f16(hn, hi, lo);
+            *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
+            *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
+            if (live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;
+        }
+    };
+#pragma unroll 1
+    for (int s = 0; s < T; ++s) {
+        // the rows of step s + 1 (requested during step s - 1) go into the other pair of x planes, and the rows of
+        // step s + 2 are requested
+        store_x((s + 1) & 1);
+        load_x(s + 2 < T ? s + 2 : T - 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4v ax[3], ah[3];
+            chain(mt, s, ax, ah);
+            gates(mt, s, ax, ah);
+        }
+        __syncthreads();
+    }
+}
+
 // Orders one wave's LDS traffic (DS operations of a wave execute in issue order: the compiler only has to
 // keep that order).
 __device__ __forceinline__ void wave_fence_lds() {
@@ -994,6 +1170,12 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
     return SEDMI_OK;
 }
 
+// SEDMI_GRU0_FUSED=0 selects the separate projection GEMM + recurrence for layer 0 (the comparison path)
+bool gru0_fused_wanted() {
+    const char *e = std::getenv("SEDMI_GRU0_FUSED");
+    return !(e && e[0] == '0');
+}
+
 int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *gi, float *rec0, float *rec1,
             hipStream_t s) {
     const long rows = n_clips * Tp;
@@ -1004,6 +1186,21 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
     float *outs[2] = {rec0, rec1};
     for (int layer = 0; layer < 2; ++layer) {
         const int K = layer == 0 ? GRU_H : 2 * GRU_H;
+        if (layer == 0 && m->precision == SEDMI_PRECISION_SPLIT_F16 && gru0_fused_wanted()) {
+            // flops: projection + recurrence; bytes: the conv output in, h out
+            sedmi::ProfileScope prof("gru0_fused", s, 2.0 * rows * 6 * GRU_H * K + 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
+                                     4.0 * rows * (GRU_H + 2.0 * GRU_H));
+            SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru0_fused_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, GRU0_LDS_BYTES));
+            const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
+            hipLaunchKernelGGL(gru0_fused_kernel, ggrid, dim3(512), GRU0_LDS_BYTES, s, in,
+                               reinterpret_cast<const uint4 *>(m->d_wihs[0]), m->wih_oscale[0], m->d_bi[0],
+                               reinterpret_cast<const uint4 *>(m->d_whhs[0]), m->whh_oscale[0], m->d_bhn[0], outs[0],
+                               n_clips, Tp);
+            SEDMI_CHECK_LAUNCH();
+            in = outs[0];
+            continue;
+        }
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj_split<128>" : "gru_input_proj_split<256>", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
