@@ -611,7 +611,11 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
             wh[g][ks] = __builtin_bit_cast(f16x8, p[0]);
             wl[g][ks] = __builtin_bit_cast(f16x8, p[2 * 3 * GRU_H]);
         }
-    const float b_hn = bhn[dir * GRU_H + j];
+    // the gates' exponentials are bare exp2: -log2(e) (sigmoid) and -2 log2(e) (tanh as 2 sigmoid(2 a) - 1) are
+    // folded into the product's output scale and into the additions of gi
+    constexpr float kC1 = -1.4426950408889634f, kC2 = -2.8853900817779268f;
+    const float sh1 = whh_oscale * kC1, sh2 = whh_oscale * kC2;
+    const float b_hn = bhn[dir * GRU_H + j] * kC2;
 
     for (int i = tid; i < static_cast<int>(sizeof(hs) / 4); i += 512) reinterpret_cast<unsigned *>(&hs[0][0][0])[i] = 0u;
     // accumulator register i of tile mt is clip 16 mt + 4 kg + i
@@ -670,14 +674,15 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
         char *nh = &hs[s & 1][0][0], *nl = &hs[s & 1][1][0];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float rg = sigmoidf_fast(fmaf(acc[0][i], whh_oscale, g[0][i]));
-            const float zg = sigmoidf_fast(fmaf(acc[1][i], whh_oscale, g[1][i]));
-            const float ng = tanhf_fast(fmaf(rg, fmaf(acc[2][i], whh_oscale, b_hn), g[2][i]));
+            const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[0][i], sh1, kC1 * g[0][i])));
+            const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[1][i], sh1, kC1 * g[1][i])));
+            const float na = fmaf(rg, fmaf(acc[2][i], sh2, b_hn), kC2 * g[2][i]);                 // -2 log2(e) * argument
+            const float ng = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(na)), -1.0f);
             const float hn = fmaf(zg, hprev[mt][i] - ng, ng);      // (1 - z) * n + z * h
             hprev[mt][i] = hn;
             const int row = 16 * mt + 4 * kg + i;
-            _Float16 hi, lo;
-            split_f16(hn, hi, lo);
+            const _Float16 hi = static_cast<_Float16>(hn);         // |h| < 1: no clamp needed
+            const _Float16 lo = static_cast<_Float16>(hn - static_cast<float>(hi));
             *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
             *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
             if (live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;
@@ -763,8 +768,12 @@ __global__ __launch_bounds__(512, 1) void gru0_fused_kernel(
         reinterpret_cast<uint4 *>(wlo)[i] =
             wih[((static_cast<long>(ks16) * 2 + 1) * (6 * GRU_H) + dir * 3 * GRU_H + g * GRU_H + unit) * 2 + (kq & 1)];
     }
-    const float b_r = bi[dir * 3 * GRU_H + j], b_z = bi[dir * 3 * GRU_H + GRU_H + j], b_in = bi[dir * 3 * GRU_H + 2 * GRU_H + j];
-    const float b_hn = bhn[dir * GRU_H + j];
+    // the gates' exponentials are bare exp2: -log2(e) (sigmoid) and -2 log2(e) (tanh as 2 sigmoid(2 a) - 1) are
+    // folded into the output scales and biases of the two products
+    constexpr float kC1 = -1.4426950408889634f, kC2 = -2.8853900817779268f;
+    const float si1 = wih_oscale * kC1, sh1 = whh_oscale * kC1, si2 = wih_oscale * kC2, sh2 = whh_oscale * kC2;
+    const float b_r = bi[dir * 3 * GRU_H + j] * kC1, b_z = bi[dir * 3 * GRU_H + GRU_H + j] * kC1;
+    const float b_in = bi[dir * 3 * GRU_H + 2 * GRU_H + j] * kC2, b_hn = bhn[dir * GRU_H + j] * kC2;
     for (int i = tid; i < 2 * GRU0_PLANES_BYTES / 4; i += 512) reinterpret_cast<unsigned *>(g0_lds)[i] = 0u;
 
     // accumulator register i of tile mt is clip 16 mt + 4 kg + i
@@ -858,14 +867,15 @@ __global__ __launch_bounds__(512, 1) void gru0_fused_kernel(
         char *nh = hpl + (s & 1) * 2 * GRU_NB * GRU_PSB, *nl = nh + GRU_NB * GRU_PSB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float rg = sigmoidf_fast(fmaf(ah[0][i], whh_oscale, fmaf(ax[0][i], wih_oscale, b_r)));
-            const float zg = sigmoidf_fast(fmaf(ah[1][i], whh_oscale, fmaf(ax[1][i], wih_oscale, b_z)));
-            const float ng = tanhf_fast(fmaf(rg, fmaf(ah[2][i], whh_oscale, b_hn), fmaf(ax[2][i], wih_oscale, b_in)));
+            const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(ah[0][i], sh1, fmaf(ax[0][i], si1, b_r))));
+            const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(ah[1][i], sh1, fmaf(ax[1][i], si1, b_z))));
+            const float na = fmaf(rg, fmaf(ah[2][i], sh2, b_hn), fmaf(ax[2][i], si2, b_in));     // -2 log2(e) * argument
+            const float ng = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(na)), -1.0f);
             const float hn = fmaf(zg, hprev[mt][i] - ng, ng);      // (1 - z) * n + z * h
             hprev[mt][i] = hn;
             const int row = 16 * mt + 4 * kg + i;
-            _Float16 hi, lo;
-            split_f16(hn, hi, lo);
+            const _Float16 hi = static_cast<_Float16>(hn);         // |h| < 1: no clamp needed
+            const _Float16 lo = static_cast<_Float16>(hn - static_cast<float>(hi));
             *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
             *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
             if (live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;

@@ -81,6 +81,35 @@ def test_gru_stage_alone_matches_reference_golden(golden_dir):
     assert np.abs(rec.cpu().numpy() - g["gru_out"]).max() < 2e-5
 
 
+def test_gru_layer0_fused_and_separate_kernels_agree(golden_dir, monkeypatch):
+    """Layer 0 runs with its input projection inside the recurrence by default
+    and as GEMM + recurrence with SEDMI_GRU0_FUSED=0: both against the
+    reference's GRU output, and against each other, on a ragged batch."""
+    from sound_event_detection_amd import _lib
+    g = np.load(os.path.join(golden_dir, "crnn_seed0.npz"))
+    m, _ = _model(0, 10)
+    ref_seq = np.ascontiguousarray(np.transpose(g["cnn_out"][..., 0], (0, 2, 1)))
+    rng = np.random.Generator(np.random.PCG64(11))
+    big = (rng.standard_normal((37, 61, 128)) * 2).astype(np.float32)       # 37 clips: a partly filled workgroup
+    lib = _lib.lib()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEDMI_GRU0_FUSED", mode)
+        for name, arr in (("ref", ref_seq), ("big", big)):
+            seq = torch.from_numpy(arr).cuda()
+            B, Tp, _ = seq.shape
+            handle = m._get_handle(seq.device)
+            ws_bytes = lib.sedmi_crnn_workspace_bytes(handle, B, 2 * Tp)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+            rec = torch.empty((B, Tp, 256), device="cuda")
+            _lib.check(lib.sedmi_crnn_gru_f32(handle, _lib.ptr(seq), B, Tp, _lib.ptr(rec), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr(seq.device)))
+            outs[mode, name] = rec.cpu().numpy()
+        assert np.abs(outs[mode, "ref"] - g["gru_out"]).max() < 2e-5
+    assert np.abs(outs["1", "big"] - outs["0", "big"]).max() < 2e-5
+    assert np.isfinite(outs["1", "big"]).all()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("B,T", [(1, 501), (5, 501), (33, 64), (70, 9), (3, 2), (2, 7501), (600, 250)])
 def test_forward_matches_oracle_on_ragged_shapes(B, T, precision):
