@@ -24,7 +24,7 @@ def bench_name(k):
     if m:
         return "gru_input_proj_split<%s>" % m.group(1)
     for a, b in (("mel_kernel", "mel_kernel"), ("conv0_kernel", "conv0_kernel"), ("conv0_split_kernel", "conv0_kernel"),
-                 ("clip_scale_kernel", "clip_scale_kernel"), ("gru_split_kernel", "gru_kernel"),
+                 ("clip_scale_kernel", "clip_scale_kernel"), ("gru0_fused_kernel", "gru0_fused"), ("gru_split_kernel", "gru_kernel"),
                  ("gru_kernel", "gru_kernel"), ("head_small_kernel", "head_kernel"), ("head_kernel", "head_kernel")):
         if k.startswith(a):
             return b
