@@ -140,8 +140,8 @@ int sedmi_crnn_destroy(sedmi_crnn *model);
  *                              bits), three f16 MFMAs per product, float32 accumulation: about
  *                              4x the relative rounding of float32 at ~5x the matrix-core rate.
  * Range in SPLIT_F16 mode.  The input features (block 0 reads the raw power mel spectrogram, whose
- * magnitude follows the audio level squared) may have ANY float32 magnitude: each clip is scaled by
- * an exact power of two to max |x| in [2^13, 2^14) before it is split, and the factor is undone
+ * magnitude follows the audio level squared) may have ANY float32 magnitude: each tile of input rows
+ * is scaled by an exact power of two to max |x| in [2^13, 2^14) before it is split, and the factor is undone
  * exactly behind the matrix product, so int16-scale PCM, loud recordings at n_fft 4096 or very quiet
  * ones lose nothing.  Activations between the layers are split as they are: a value of magnitude
  * >= 65504 there saturates.  With BatchNorm statistics that belong to the features being fed (any

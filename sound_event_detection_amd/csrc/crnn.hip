@@ -173,42 +173,6 @@ __global__ __launch_bounds__(256, 2) void conv0_kernel(const float *__restrict__
 // the biases enter as the initial accumulator.  The contraction runs over two patch rows x four patch
 // columns per lane half (12 real taps' worth of slots for 9 taps: the column the member does not cover meets a
 // zero weight), which lets the four members share their split patch rows.
-// Per-clip power-of-two scale for the split-f16 block 0.  Block 0 reads the raw features (the power mel
-// spectrogram: no log, no normalisation in front of it), whose magnitude follows the audio's level squared --
-// int16-scale PCM or a loud recording puts them beyond the f16 range (65504), a quiet one far down in the f16
-// subnormals where the hi/lo split loses its bits.  Each clip is therefore brought to max |x| in [2^13, 2^14)
-// by an exact power of two before the split, and the factor is undone, exactly again, behind the matrix
-// product (the initial accumulator -- the biases -- is scaled along).  scale[clip] = (2^-E, 2^E); E = 0 for an
-// all-zero or non-finite clip; |E| <= 60.
-__global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict__ x, long floats_per_clip,
-                                                         float2 *__restrict__ scale) {
-    const float4 *xc = reinterpret_cast<const float4 *>(x + blockIdx.x * floats_per_clip);   // floats_per_clip % 4 == 0
-    unsigned mx = 0;
-    for (long i = threadIdx.x; i < floats_per_clip / 4; i += 256) {
-        const float4 v = xc[i];
-        const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
-        const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
-        mx = max(mx, max(max(a, b), max(c, d)));      // |x| as integers: same order as the floats, NaN / inf on top
-    }
-    __shared__ unsigned red[256];
-    red[threadIdx.x] = mx;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const unsigned m = red[0];
-        int E = 0;
-        if (m != 0 && m < 0x7f800000u) {
-            const int e = static_cast<int>(m >> 23) - 127;           // floor(log2 max|x|) (-127 for subnormals)
-            E = e - 13;
-            E = E < -60 ? -60 : (E > 60 ? 60 : E);
-        }
-        scale[blockIdx.x] = make_float2(__builtin_ldexpf(1.0f, -E), __builtin_ldexpf(1.0f, E));
-    }
-}
-
 #ifndef C0_TH_V
 #define C0_TH_V 8
 #endif
@@ -223,7 +187,6 @@ __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *_
                                                           const uint4 *__restrict__ wpk,     // [2 dx][2 planes][32 rows][16] f16
                                                           const float *__restrict__ bias32,  // [32] scaled row biases
                                                           float zscale, float lscale,        // 2^-Sz, 2^-Sl
-                                                          const float2 *__restrict__ clip_scale,   // per clip (2^-E, 2^E)
                                                           float *__restrict__ y, int T, int Tp, int tiles_per_clip) {
     // x [clip][T][128], y [clip][Tp][64][16]
     __shared__ __attribute__((aligned(16))) float lds[(C0_ROWS + 4) * C0_RS];   // + 4 rows of zeros
@@ -232,16 +195,47 @@ __global__ __launch_bounds__(256, C0_OCC) void conv0_split_kernel(const float *_
     const long clip = blockIdx.x / tiles_per_clip;
     const int h20 = static_cast<int>(blockIdx.x % tiles_per_clip) * C0_TH;
     const float *xc = x + clip * static_cast<long>(T) * 128;
-    // the clip's features times 2^-E (exact) on their way into LDS; 2^E comes back with the output scales
-    const float2 cs = clip_scale[clip];
-    const float s_in = cs.x;
-    zscale *= cs.y;
-    lscale *= cs.y;
-    for (int i = tid; i < C0_ROWS * 32; i += 256) {
-        const int rr = i >> 5, c4 = (i & 31) * 4, hr = 2 * h20 - 1 + rr;
+    // The tile's features times 2^-E (exact) on their way into LDS; 2^E comes back with the output scales.  E is the
+    // tile's own: block 0 reads the raw features (the power mel spectrogram: no log, no normalisation in front of
+    // it), whose magnitude follows the audio's level squared -- int16-scale PCM or a loud recording puts them beyond
+    // the f16 range (65504), a quiet one far down in the f16 subnormals where the hi/lo split loses its bits.  The
+    // staged rows are therefore brought to max |x| in [2^13, 2^14) by an exact power of two before the split, and
+    // the factor is undone, exactly again, behind the matrix product (the initial accumulator -- the biases -- is
+    // scaled along).  E = 0 for an all-zero or non-finite tile; |E| <= 60.
+    constexpr int C0_NLD = (C0_ROWS * 32 + 255) / 256;
+    float4 stage[C0_NLD];
+    unsigned mx = 0u;
+#pragma unroll
+    for (int jn = 0; jn < C0_NLD; ++jn) {
+        const int i = tid + 256 * jn, rr = i >> 5, c4 = (i & 31) * 4, hr = 2 * h20 - 1 + rr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hr >= 0 && hr < T) v = *reinterpret_cast<const float4 *>(xc + static_cast<long>(hr) * 128 + c4);
-        *reinterpret_cast<float4 *>(&lds[rr * C0_RS + C0_HO + c4]) = make_float4(v.x * s_in, v.y * s_in, v.z * s_in, v.w * s_in);
+        if (i < C0_ROWS * 32 && hr >= 0 && hr < T) v = *reinterpret_cast<const float4 *>(xc + static_cast<long>(hr) * 128 + c4);
+        stage[jn] = v;
+        const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+        const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+        mx = max(mx, max(max(a, b), max(c, d)));      // |x| as integers: same order as the floats, NaN / inf on top
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, static_cast<unsigned>(__shfl_xor(static_cast<int>(mx), o)));
+    __shared__ unsigned tile_max[4];
+    if (lane == 0) tile_max[wave] = mx;
+    __syncthreads();
+    const unsigned m = __builtin_amdgcn_readfirstlane(max(max(tile_max[0], tile_max[1]), max(tile_max[2], tile_max[3])));
+    int E = 0;
+    if (m != 0 && m < 0x7f800000u) {
+        const int e = static_cast<int>(m >> 23) - 127;               // floor(log2 max|x|) (-127 for subnormals)
+        E = e - 13;
+        E = E < -60 ? -60 : (E > 60 ? 60 : E);
+    }
+    const float s_in = __builtin_ldexpf(1.0f, -E), s_out = __builtin_ldexpf(1.0f, E);
+    zscale *= s_out;
+    lscale *= s_out;
+#pragma unroll
+    for (int jn = 0; jn < C0_NLD; ++jn) {
+        const int i = tid + 256 * jn, rr = i >> 5, c4 = (i & 31) * 4;
+        const float4 v = stage[jn];
+        if (i < C0_ROWS * 32)
+            *reinterpret_cast<float4 *>(&lds[rr * C0_RS + C0_HO + c4]) = make_float4(v.x * s_in, v.y * s_in, v.z * s_in, v.w * s_in);
     }
     for (int i = tid; i < C0_ROWS * 2; i += 256) lds[(i >> 1) * C0_RS + ((i & 1) ? C0_HO + 128 : C0_HO - 1)] = 0.f;
     for (int i = tid; i < 4 * C0_RS; i += 256) lds[C0_ROWS * C0_RS + i] = 0.f;
@@ -1104,7 +1098,6 @@ int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, 
 
 struct Scratch {
     float *actA, *actB, *seq, *gi, *rec0, *rec1;
-    float2 *clip_scale;
     size_t bytes;
 };
 
@@ -1120,7 +1113,6 @@ Scratch carve(void *ws, long n_clips, long Tp, bool with_cnn, bool with_gru) {
     if (with_cnn) {
         sc.actA = take(static_cast<size_t>(ch) * Tp * 1024);
         sc.actB = take(static_cast<size_t>(ch) * Tp * 1024);
-        sc.clip_scale = reinterpret_cast<float2 *>(take(static_cast<size_t>(ch) * 2));
     }
     if (with_gru) {
         sc.seq = take(static_cast<size_t>(n_clips) * Tp * GRU_H);
@@ -1133,19 +1125,13 @@ Scratch carve(void *ws, long n_clips, long Tp, bool with_cnn, bool with_gru) {
 }
 
 int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float *seq, float *actA, float *actB,
-            float2 *clip_scale, hipStream_t s) {
+            hipStream_t s) {
     const int Tp = T / 2;
     for (long c0 = 0; c0 < n_clips; c0 += kCnnChunk) {
         const long nc = std::min<long>(kCnnChunk, n_clips - c0);
         const float *x = feats + c0 * static_cast<long>(T) * 128;
         const long total0 = nc * Tp * 64;
         const unsigned grid0 = static_cast<unsigned>(sedmi::ceil_div(total0, 256));
-        if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
-            sedmi::ProfileScope prof("clip_scale_kernel", s, 0.0, 4.0 * nc * static_cast<double>(T) * 128);
-            hipLaunchKernelGGL(clip_scale_kernel, dim3(static_cast<unsigned>(nc)), dim3(256), 0, s, x,
-                               static_cast<long>(T) * 128, clip_scale);
-            SEDMI_CHECK_LAUNCH();
-        }
         {
             const double pos = static_cast<double>(nc) * (2.0 * Tp) * 128;
             sedmi::ProfileScope prof("conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
@@ -1154,7 +1140,7 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
                 const int tiles = static_cast<int>(sedmi::ceil_div(Tp, C0_TH));
                 hipLaunchKernelGGL(conv0_split_kernel, dim3(static_cast<unsigned>(nc * tiles)), dim3(256), 0, s, x,
                                    reinterpret_cast<const uint4 *>(m->d_c0s), m->d_c0bias, m->c0_zscale, m->c0_lscale,
-                                   clip_scale, actA, T, Tp, tiles);
+                                   actA, T, Tp, tiles);
             } else {
                 hipLaunchKernelGGL(conv0_kernel, dim3(grid0), dim3(256), 0, s, x, m->d_c0, actA, nc, T, 128, Tp);
             }
@@ -1505,7 +1491,7 @@ int sedmi_crnn_cnn_f32(const sedmi_crnn *m, const float *feats, int64_t n_clips,
     SEDMI_REQUIRE(feats && seq && ws, "null data pointer");
     Scratch sc = carve(ws, n_clips, T / 2, true, false);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
-    return run_cnn(m, feats, n_clips, static_cast<int>(T), seq, sc.actA, sc.actB, sc.clip_scale,
+    return run_cnn(m, feats, n_clips, static_cast<int>(T), seq, sc.actA, sc.actB,
                    static_cast<hipStream_t>(stream));
 }
 
@@ -1555,7 +1541,7 @@ int sedmi_crnn_forward_f32(const sedmi_crnn *m, const float *feats, int64_t n_cl
     Scratch sc = carve(ws, n_clips, Tp, true, true);
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = run_cnn(m, feats, n_clips, static_cast<int>(T), sc.seq, sc.actA, sc.actB, sc.clip_scale, s))) return rc;
+    if ((rc = run_cnn(m, feats, n_clips, static_cast<int>(T), sc.seq, sc.actA, sc.actB, s))) return rc;
     if ((rc = run_gru(m, sc.seq, n_clips, Tp, sc.gi, sc.rec0, sc.rec1, s))) return rc;
     return sedmi_crnn_head_f32(m, sc.rec1, n_clips * Tp, probs, stream);
 }
