@@ -83,6 +83,14 @@ int sedmi_melspec_f32(const sedmi_mel_plan *plan, const float *y, int64_t n_clip
                       int64_t n_samples, int flags, const float *mean, const float *istd,
                       float *out, void *stream);
 
+/* The same from 16-bit PCM as a WAV file holds it (device int16 [n_clips, n_samples]): each sample is
+ * taken as sample / 32768, which is exact in float32, so the output is bit for bit the one
+ * sedmi_melspec_f32 gives for the converted samples (librosa.load at feature_extraction.py:37 does
+ * that conversion on the CPU and hands float32 on).  Half the bytes across PCIe and from HBM. */
+int sedmi_melspec_i16(const sedmi_mel_plan *plan, const int16_t *y, int64_t n_clips,
+                      int64_t n_samples, int flags, const float *mean, const float *istd,
+                      float *out, void *stream);
+
 /* Per-mel-bin sum and sum of squares over all clips and frames of a
  * [n_clips, n_mels, T] array, accumulated in float64 into device buffers
  * sum[n_mels], sumsq[n_mels] (ADDED to their current contents, so that ranks

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sedmi_mel_num_frames": (_I64, [_VP, _I64]),
     "sedmi_mel_filterbank": (_I, [_VP, _VP]),
     "sedmi_melspec_f32": (_I, [_VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
+    "sedmi_melspec_i16": (_I, [_VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "sedmi_mel_stats_f64": (_I, [_VP, _I64, _I, _I64, _VP, _VP, _VP]),
     "sedmi_crnn_create": (_I, [C.POINTER(_VP), C.POINTER(CrnnWeights)]),
     "sedmi_crnn_destroy": (_I, [_VP]),

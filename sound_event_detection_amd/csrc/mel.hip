@@ -34,7 +34,7 @@
 namespace {
 
 struct MelArgs {
-    const float *y;
+    const void *y;           // float32 samples, or int16 PCM (taken as sample / 32768) in the I16 instances
     long n_samples;
     int T;
     int hop;
@@ -173,7 +173,7 @@ struct MelGeom {
 // and applies the filterbank to it (lane = a pair of filters), so there is no workgroup barrier in the frame
 // loop and the LDS footprint is the scratch alone (three 4-wave workgroups per CU at n_fft 2048:
 // three waves per SIMD to cover the LDS round trips of the transposes).
-template <int R1, int WAVES, int ROW0, int NROW>
+template <int R1, int WAVES, int ROW0, int NROW, bool I16>
 __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(const MelArgs a) {
     using G = MelGeom<R1>;
     constexpr int NC = G::NC;
@@ -254,18 +254,27 @@ __global__ __launch_bounds__(WAVES * 64, (NROW < R1 ? 3 : 1)) void mel_kernel(co
     // unsigned ones) and past its end read as zero -- the centred frames' padding -- with no branch, and a
     // frame that does not exist gets an empty descriptor
     auto load_raw = [&](bool live, unsigned clip, int t, float (&r0)[NROW], float (&r1)[NROW]) {
+        constexpr unsigned SB = I16 ? 2u : 4u;               // bytes per sample
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.y) + static_cast<long>(live ? clip : 0) * a.n_samples, 0, live ? static_cast<int>(static_cast<unsigned>(a.n_samples) * 4u) : 0,
-            0x00020000);
+            const_cast<char *>(static_cast<const char *>(a.y)) + static_cast<long>(live ? clip : 0) * a.n_samples * SB, 0,
+            live ? static_cast<int>(static_cast<unsigned>(a.n_samples) * SB) : 0, 0x00020000);
         // byte offset of this lane's first sample, modulo 2^32
-        const unsigned s0 = (static_cast<unsigned>(t) * a.hop - a.n_fft / 2 + 2 * (64 * ROW0 + lane)) * 4u;
+        const unsigned s0 = (static_cast<unsigned>(t) * a.hop - a.n_fft / 2 + 2 * (64 * ROW0 + lane)) * SB;
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
             // each offset is clamped on its own: with an odd hop a pair can be (sample -1, sample 0), whose offsets
-            // are 2^32 - 4 and 0 -- two loads the compiler must not fuse into one 8-byte access
-            const unsigned o0 = s0 + i * 512, o1 = o0 + 4;
-            r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(o0 < 0xfffffff0u ? o0 : 0xfffffff0u), 0, 0));
-            r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, static_cast<int>(o1 < 0xfffffff0u ? o1 : 0xfffffff0u), 0, 0));
+            // are 2^32 - 4 and 0 -- two loads the compiler must not fuse into one wider access
+            const unsigned o0 = s0 + i * 128 * SB, o1 = o0 + SB;
+            const int c0 = static_cast<int>(o0 < 0xfffffff0u ? o0 : 0xfffffff0u), c1 = static_cast<int>(o1 < 0xfffffff0u ? o1 : 0xfffffff0u);
+            if constexpr (I16) {
+                // PCM as the WAV file holds it: sample / 32768 is exact in float32, so the result is the one the
+                // float32 entry point gives for the converted samples
+                r0[i] = static_cast<float>(static_cast<short>(__builtin_amdgcn_raw_buffer_load_b16(rs, c0, 0, 0))) * (1.0f / 32768.0f);
+                r1[i] = static_cast<float>(static_cast<short>(__builtin_amdgcn_raw_buffer_load_b16(rs, c1, 0, 0))) * (1.0f / 32768.0f);
+            } else {
+                r0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, c0, 0, 0));
+                r1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, c1, 0, 0));
+            }
         }
     };
     float raw0[NROW], raw1[NROW];
@@ -699,7 +708,7 @@ int sedmi_mel_filterbank(const sedmi_mel_plan *p, float *host_out) {
 
 }  // extern "C"
 
-template <int R1, int WAVES, int ROW0 = 0, int NROW = R1>
+template <int R1, int WAVES, bool I16, int ROW0 = 0, int NROW = R1>
 static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStream_t stream) {
     a.tiles_per_clip = static_cast<int>(sedmi::ceil_div(a.T, 32));     // work items: blocks of 32 frames
     a.total_tiles = n_clips * a.tiles_per_clip;
@@ -707,7 +716,7 @@ static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStre
                   a.total_tiles);
     const size_t lds = mel_lds_bytes<R1, WAVES>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
-    auto kern = mel_kernel<R1, WAVES, ROW0, NROW>;
+    auto kern = mel_kernel<R1, WAVES, ROW0, NROW, I16>;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const long per_cu = std::max<long>(1, std::min<long>(8, (160 * 1024) / static_cast<long>(lds)));
@@ -716,16 +725,15 @@ static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStre
     sedmi::ProfileScope prof("mel_kernel", stream,
                              frames * (2.5 * p->n_fft * std::log2(static_cast<double>(p->n_fft)) + 3.0 * p->n_bins +
                                        2.0 * p->nnz_real),
-                             4.0 * (static_cast<double>(n_clips) * a.n_samples + frames * p->n_mels));
+                             (I16 ? 2.0 : 4.0) * static_cast<double>(n_clips) * a.n_samples + 4.0 * frames * p->n_mels);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(WAVES * 64), lds, stream, a);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
 
-extern "C" {
-
-int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, int64_t n_samples,
-                      int flags, const float *mean, const float *istd, float *out, void *stream) {
+template <bool I16>
+static int melspec(const sedmi_mel_plan *p, const void *y, int64_t n_clips, int64_t n_samples, int flags,
+                   const float *mean, const float *istd, float *out, void *stream) {
     SEDMI_REQUIRE(p != nullptr, "plan is null");
     SEDMI_REQUIRE(n_clips >= 0 && n_samples >= 0, "negative size");
     SEDMI_REQUIRE((flags & ~(SEDMI_MEL_LOG | SEDMI_MEL_NORMALISE)) == 0, "unknown flags 0x%x", flags);
@@ -742,13 +750,25 @@ int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, 
     a.mel_w = p->d_w; a.nnz = p->nnz; a.out = out; a.flags = flags; a.mean = mean; a.istd = istd;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->n_fft) {
-        case 1024: return launch_mel<8, 4>(p, a, n_clips, s);
+        case 1024: return launch_mel<8, 4, I16>(p, a, n_clips, s);
         case 2048:
             // window confined to first-stage rows 5..10 (e.g. win 640): specialised instance
-            if (p->zlo >= 5 * 64 && p->zhi <= 11 * 64) return launch_mel<16, 4, 5, 6>(p, a, n_clips, s);
-            return launch_mel<16, 4>(p, a, n_clips, s);
-        default:   return launch_mel<32, 4>(p, a, n_clips, s);
+            if (p->zlo >= 5 * 64 && p->zhi <= 11 * 64) return launch_mel<16, 4, I16, 5, 6>(p, a, n_clips, s);
+            return launch_mel<16, 4, I16>(p, a, n_clips, s);
+        default:   return launch_mel<32, 4, I16>(p, a, n_clips, s);
     }
+}
+
+extern "C" {
+
+int sedmi_melspec_f32(const sedmi_mel_plan *p, const float *y, int64_t n_clips, int64_t n_samples,
+                      int flags, const float *mean, const float *istd, float *out, void *stream) {
+    return melspec<false>(p, y, n_clips, n_samples, flags, mean, istd, out, stream);
+}
+
+int sedmi_melspec_i16(const sedmi_mel_plan *p, const int16_t *y, int64_t n_clips, int64_t n_samples,
+                      int flags, const float *mean, const float *istd, float *out, void *stream) {
+    return melspec<true>(p, y, n_clips, n_samples, flags, mean, istd, out, stream);
 }
 
 int sedmi_mel_stats_f64(const float *mel, int64_t n_clips, int n_mels, int64_t T, double *sum,

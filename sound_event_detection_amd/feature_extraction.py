@@ -83,8 +83,8 @@ def melspectrogram(y: torch.Tensor, sr: int, n_fft: int, n_mels: int, hop_length
     does not have (10*log10(max(S,1e-10)); per-mel-bin standardisation)."""
     if not y.is_cuda:
         raise _lib.SedmiError("melspectrogram needs a CUDA (ROCm) tensor; there is no CPU path")
-    if y.dtype != torch.float32:
-        raise TypeError("melspectrogram expects float32 audio")
+    if y.dtype not in (torch.float32, torch.int16):
+        raise TypeError("melspectrogram expects float32 audio or int16 PCM (taken as sample / 32768)")
     squeeze = y.dim() == 1
     if squeeze:
         y = y.unsqueeze(0)
@@ -106,10 +106,10 @@ def melspectrogram(y: torch.Tensor, sr: int, n_fft: int, n_mels: int, hop_length
         flags |= _lib.SEDMI_MEL_NORMALISE
         mean = mean.to(y.device, torch.float32).contiguous()
         istd = (1.0 / std.to(y.device, torch.float32)).contiguous()
+    entry = "sedmi_melspec_i16" if y.dtype == torch.int16 else "sedmi_melspec_f32"
     with torch.cuda.device(y.device):
-        _lib.check(_lib.lib().sedmi_melspec_f32(plan.handle, _lib.ptr(y), B, N, flags, _lib.ptr(mean),
-                                                _lib.ptr(istd), _lib.ptr(out), _lib.stream_ptr(y.device)),
-                   "sedmi_melspec_f32")
+        _lib.check(getattr(_lib.lib(), entry)(plan.handle, _lib.ptr(y), B, N, flags, _lib.ptr(mean),
+                                              _lib.ptr(istd), _lib.ptr(out), _lib.stream_ptr(y.device)), entry)
     res = out.view(B, n_mels, T)
     return res[0] if squeeze else res
 

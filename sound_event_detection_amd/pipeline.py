@@ -130,7 +130,7 @@ class SedPipeline:
         return res
 
     def run(self, y: torch.Tensor, clips_per_recording=None, cutoffs=None, alphas=None):
-        """y: float32 CUDA tensor [B, N] of equally long clips; consecutive clips
+        """y: float32 (or int16 PCM, taken as sample / 32768) CUDA tensor [B, N] of equally long clips; consecutive clips
         of one recording are decoded as one frame sequence (training.py:350).
         ``alphas``: the three ShakeShake mixing weights for the Shake models
         (drawn as the reference draws them when None).
@@ -138,17 +138,18 @@ class SedPipeline:
         int32 [4, cap] (recording, class, onset frame, offset frame) and
         ``n_events`` [1], all on the device and valid once the stream has
         drained; they are overwritten by the next run."""
-        if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2 or not y.is_contiguous():
-            raise ValueError("y must be a contiguous float32 CUDA tensor [clips, samples]")
+        if not y.is_cuda or y.dtype not in (torch.float32, torch.int16) or y.dim() != 2 or not y.is_contiguous():
+            raise ValueError("y must be a contiguous float32 or int16 CUDA tensor [clips, samples]")
         B, N = y.shape
         dev = y.device
         plan = fe.get_plan(self.sr, self.n_fft, self.win, self.hop, self.n_mels, dev)
         T = plan.num_frames(N)
         b = self._buffers(B, T, dev, True)
         mel = b["mel"][:B]
+        entry = "sedmi_melspec_i16" if y.dtype == torch.int16 else "sedmi_melspec_f32"
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().sedmi_melspec_f32(plan.handle, _lib.ptr(y), B, N, 0, None, None, _lib.ptr(mel),
-                                                    _lib.stream_ptr(dev)), "sedmi_melspec_f32")
+            _lib.check(getattr(_lib.lib(), entry)(plan.handle, _lib.ptr(y), B, N, 0, None, None, _lib.ptr(mel),
+                                                  _lib.stream_ptr(dev)), entry)
         # the [B, n_mels, T] bytes are the [B, T, n_mels] feature (feature_extraction.py:49-50)
         res = self._model_and_decode(b, _lib.ptr(mel), B, T, dev, clips_per_recording, cutoffs, alphas)
         res["mel"] = mel
