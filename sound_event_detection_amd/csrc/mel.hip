@@ -646,7 +646,7 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
     p->n_pairs = 64 * ((n_mels + 127) / 128);
     std::vector<int> meta(static_cast<size_t>(5) * p->n_pairs, 0);
     std::vector<float> wsp;
-    unsigned used_groups = 0;
+    unsigned used_groups[4] = {0, 0, 0, 0};
     for (int mp = 0; mp < p->n_pairs; ++mp) {
         const int first = 128 * (mp / 64), C = std::min(128, n_mels - first), l = mp % 64;
         const int fa = l < (C + 1) / 2 ? first + l : -1;
@@ -655,13 +655,16 @@ int sedmi_mel_plan_create(sedmi_mel_plan **out, int sr, int n_fft, int win_lengt
         // power spectrum) and is zero-padded at both ends to a multiple of eight bins
         const int sa = fa >= 0 ? start[fa] & ~3 : 0, sb = fb >= 0 ? start[fb] & ~3 : 0;
         const int la = fa >= 0 ? (len[fa] + start[fa] - sa + 7) & ~7 : 0, lb = fb >= 0 ? (len[fb] + start[fb] - sb + 7) & ~7 : 0;
-        // the 16-byte weight reads that 16 neighbouring lanes issue together should fall into 16 different groups
-        // of four LDS banks: start each run at the first multiple of four floats whose bank group no other pair of
-        // its 16-group uses yet
-        if (mp % 16 == 0) used_groups = 0;
+        // A 16-byte LDS read is served in four groups of 16 lanes (lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
+        // of each half wave), and inside a group the 16 reads should fall into 16 different quads of banks: start
+        // each run at the first multiple of four floats whose bank quad no other lane of its group uses yet (all
+        // lanes advance by the same eight floats per trip, so the quads stay distinct through the loop)
+        const int lane = mp % 64, l32 = lane % 32;
+        const int group = 2 * (lane / 32) + ((l32 < 4 || (l32 >= 12 && l32 < 16) || (l32 >= 20 && l32 < 28)) ? 0 : 1);
+        if (lane == 0) used_groups[0] = used_groups[1] = used_groups[2] = used_groups[3] = 0;
         while (wsp.size() % 4) wsp.push_back(0.f);
-        while (used_groups >> ((wsp.size() / 4) % 16) & 1u) wsp.insert(wsp.end(), 4, 0.f);
-        used_groups |= 1u << ((wsp.size() / 4) % 16);
+        while (used_groups[group] >> ((wsp.size() / 4) % 16) & 1u) wsp.insert(wsp.end(), 4, 0.f);
+        used_groups[group] |= 1u << ((wsp.size() / 4) % 16);
         const int ptr = static_cast<int>(wsp.size());
         // (bins outside [start, start + len) of the filter's dense row are zero)
         for (int k = 0; k < la; ++k)
