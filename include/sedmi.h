@@ -171,7 +171,10 @@ size_t sedmi_crnn_workspace_bytes(const sedmi_crnn *model, int64_t n_clips, int6
 int sedmi_crnn_forward_f32(const sedmi_crnn *model, const float *feats, int64_t n_clips,
                            int64_t T, float *probs, void *ws, size_t ws_bytes, void *stream);
 
-/* Stage-level entry points (same arithmetic as inside the full forward; used
+/* Stage-level entry points (same arithmetic as inside the full forward, except
+ * that the full forward in SPLIT_F16 mode with at most 16 classes forms the
+ * head's products inside the last GRU layer, in split-f16 arithmetic, where
+ * sedmi_crnn_head_f32 uses the float32 matrix instruction: ~1e-7 apart; used
  * by the layer-level parity tests).
  * sedmi_crnn_cnn_f32:  feats [n, T, n_freq] -> seq [n, T', C_last]
  *   (= CNN.forward + squeeze(-1).permute(0,2,1), nnet/CRNN.py:200,212-213).

@@ -580,13 +580,21 @@ __global__ __launch_bounds__(256, 1) void gru_kernel(
 constexpr int GRU_PSB = GRU_H * 2 + 16;      // bytes per clip row of one h plane
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+// HEAD: the kernel is the last recurrent layer of a model with at most 16 classes and forms its direction's share of
+// the head's logits itself, h . Wd[:, dir half]^T, instead of writing h out for a separate head kernel to read back
+// (1 GB each way per 4096 clips): the A fragments a wave loads for the products of step s are h of step s - 1 for
+// all 128 units, so wave mt adds twelve MFMAs per step for tile mt and stores 16 floats per clip and step.
+template <bool HEAD>
 __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     const float *__restrict__ gi,      // [clip][T][2][3H]
     const uint4 *__restrict__ whh,     // packed split [2][H/16][2 planes][3H][16] f16, pre-scaled by 2^S
     float whh_oscale,                  // 2^-S
     const float *__restrict__ bhn,     // [2][H]
-    float *__restrict__ out,           // [clip][T][2H]
-    long n_clips, int T) {
+    float *__restrict__ out,           // [clip][T][2H] (not written with HEAD)
+    long n_clips, int T,
+    const uint4 *__restrict__ wds,     // HEAD: packed split [2][H/16][2 planes][16 classes][16] f16, times 2^Sd
+    float wd_oscale,                   // 2^-Sd
+    float *__restrict__ plog) {        // HEAD: [2][clip][T][16] partial logits
     __shared__ __attribute__((aligned(16))) char hs[2][2][GRU_NB * GRU_PSB];     // [buffer][plane]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;        // column (A: row) within a 16-wide tile; k-group / row group
@@ -610,6 +618,33 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
     constexpr float kC1 = -1.4426950408889634f, kC2 = -2.8853900817779268f;
     const float sh1 = whh_oscale * kC1, sh2 = whh_oscale * kC2;
     const float b_hn = bhn[dir * GRU_H + j] * kC2;
+    // head weights of this direction's half in LDS, in the order the B fragments are read back: 16-byte piece
+    // number ((ks * 2 + plane) * 16 + class) * 4 + kg (HEAD only; registers are too scarce to keep them there)
+    __shared__ __attribute__((aligned(16))) uint4 wd_lds[HEAD ? (GRU_H / 32) * 2 * 16 * 4 : 1];
+    if constexpr (HEAD) {
+        for (int i = tid; i < (GRU_H / 32) * 2 * 16 * 4; i += 512) {
+            const int kq = i & 3, cls = (i >> 2) & 15, plane = (i >> 6) & 1, ks = i >> 7;
+            const int ks16 = 2 * ks + (kq >> 1);
+            wd_lds[i] = wds[((static_cast<long>(dir) * (GRU_H / 16) + ks16) * 2 + plane) * 16 * 2 + cls * 2 + (kq & 1)];
+        }
+    }
+    // partial logits of tile mt at time index t from the A fragments of h: rows = clips 16 mt + 4 kg + i, column = class
+    auto head_part = [&](int mt, long t, const f16x8 (&vah)[GRU_H / 32], const f16x8 (&val)[GRU_H / 32]) {
+        f32x4v al = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < GRU_H / 32; ++ks) {
+            const f16x8 dh = __builtin_bit_cast(f16x8, wd_lds[((ks * 2 + 0) * 16 + n16) * 4 + kg]);
+            const f16x8 dl = __builtin_bit_cast(f16x8, wd_lds[((ks * 2 + 1) * 16 + n16) * 4 + kg]);
+            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(val[ks], dh, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[ks], dl, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[ks], dh, al, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long b = b0 + 16 * mt + 4 * kg + i;
+            if (b < n_clips) plog[((static_cast<long>(dir) * n_clips + b) * T + t) * 16 + n16] = al[i] * wd_oscale;
+        }
+    };
 
     for (int i = tid; i < static_cast<int>(sizeof(hs) / 4); i += 512) reinterpret_cast<unsigned *>(&hs[0][0][0])[i] = 0u;
     // accumulator register i of tile mt is clip 16 mt + 4 kg + i
@@ -662,6 +697,9 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
 #pragma unroll
             for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[ks], wh[q][ks], acc[q], 0, 0, 0);
         }
+        if constexpr (HEAD) {
+            if (wave == mt && s > 0) head_part(mt, dir ? T - s : s - 1, vah, val);     // h of the previous step
+        }
     };
     auto gates = [&](int mt, int s, const f32x4v (&acc)[3], const float (&g)[3][4]) {
         const long t = dir ? T - 1 - s : s;
@@ -679,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
             const _Float16 lo = static_cast<_Float16>(hn - static_cast<float>(hi));
             *reinterpret_cast<_Float16 *>(nh + row * GRU_PSB + j * 2) = hi;
             *reinterpret_cast<_Float16 *>(nl + row * GRU_PSB + j * 2) = lo;
-            if (live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;
+            if (!HEAD && live[mt][i]) outp[mt][i][t * (2 * GRU_H)] = hn;
         }
     };
     // one 16-clip tile at a time: chain, then gates (the next tile's chain of this wave and the other wave's
@@ -707,6 +745,32 @@ __global__ __launch_bounds__(512, 1) void gru_split_kernel(
             for (int q = 0; q < 3; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[mt][q][i] = gn[mt][q][i];
+    }
+    if constexpr (HEAD) {
+        // the last step's h (complete behind the loop's last barrier) still owes its logits
+        if (wave < 2) {
+            const int mt = wave, rd = (T - 1) & 1;
+            const char *ah = &hs[rd][0][(16 * mt + n16) * GRU_PSB + 16 * kg], *al = &hs[rd][1][(16 * mt + n16) * GRU_PSB + 16 * kg];
+            f16x8 vah[GRU_H / 32], val[GRU_H / 32];
+#pragma unroll
+            for (int ks = 0; ks < GRU_H / 32; ++ks) {
+                vah[ks] = *reinterpret_cast<const f16x8 *>(ah + ks * 64);
+                val[ks] = *reinterpret_cast<const f16x8 *>(al + ks * 64);
+            }
+            head_part(mt, dir ? 0 : T - 1, vah, val);
+        }
+    }
+}
+
+// probabilities from the two directions' partial logits: sigmoid(fwd + bwd + bias)
+__global__ __launch_bounds__(256) void head_combine_kernel(const float *__restrict__ plog, const float *__restrict__ bd,
+                                                           float *__restrict__ probs, long n_rows, int n_cls) {
+    const long total = n_rows * n_cls;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+        const long r = i / n_cls;
+        const int c = static_cast<int>(i - r * n_cls);
+        const float v = plog[r * 16 + c] + plog[(n_rows + r) * 16 + c] + bd[c];
+        probs[i] = 1.0f / (1.0f + expf(-v));
     }
 }
 
@@ -1042,6 +1106,8 @@ struct sedmi_crnn {
     uint16_t *d_wps[SEDMI_CRNN_LAYERS] = {}, *d_gps[SEDMI_CRNN_LAYERS] = {};
     float *d_ss[SEDMI_CRNN_LAYERS] = {}, *d_ts[SEDMI_CRNN_LAYERS] = {}, *d_gs[SEDMI_CRNN_LAYERS] = {}, *d_gbh[SEDMI_CRNN_LAYERS] = {};
     uint16_t *d_wihs[2] = {};          // split-f16 GRU input-projection weights
+    uint16_t *d_wds = nullptr;         // split-f16 head weights per direction half (only for <= 16 classes)
+    float wd_oscale = 1.f;
     float wih_oscale[2] = {1.f, 1.f};
     uint16_t *d_whhs[2] = {};          // split-f16 GRU recurrent weights, both directions
     float whh_oscale[2] = {1.f, 1.f};
@@ -1166,14 +1232,22 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
     return SEDMI_OK;
 }
 
+// SEDMI_HEAD_FUSED=0 keeps the head as a kernel of its own behind layer 1 (the comparison path)
+bool head_fused_wanted() {
+    const char *e = std::getenv("SEDMI_HEAD_FUSED");
+    return !(e && e[0] == '0');
+}
+
 // SEDMI_GRU0_FUSED=0 selects the separate projection GEMM + recurrence for layer 0 (the comparison path)
 bool gru0_fused_wanted() {
     const char *e = std::getenv("SEDMI_GRU0_FUSED");
     return !(e && e[0] == '0');
 }
 
+// plog != nullptr (split precision, at most 16 classes): layer 1 leaves its partial logits there
+// ([2][clip][Tp][16]) and writes no rec1
 int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *gi, float *rec0, float *rec1,
-            hipStream_t s) {
+            hipStream_t s, float *plog = nullptr) {
     const long rows = n_clips * Tp;
     const size_t lds = sizeof(float) * 128 * 132;
     SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_kernel),
@@ -1230,9 +1304,16 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
                                      4.0 * rows * (6.0 * GRU_H + 2.0 * GRU_H));
             const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
             if (m->precision == SEDMI_PRECISION_SPLIT_F16)
-                hipLaunchKernelGGL(gru_split_kernel, ggrid, dim3(512), 0, s, gi,
-                                   reinterpret_cast<const uint4 *>(m->d_whhs[layer]), m->whh_oscale[layer],
-                                   m->d_bhn[layer], outs[layer], n_clips, Tp);
+                if (layer == 1 && plog)
+                    hipLaunchKernelGGL(gru_split_kernel<true>, ggrid, dim3(512), 0, s, gi,
+                                       reinterpret_cast<const uint4 *>(m->d_whhs[layer]), m->whh_oscale[layer],
+                                       m->d_bhn[layer], static_cast<float *>(nullptr), n_clips, Tp,
+                                       reinterpret_cast<const uint4 *>(m->d_wds), m->wd_oscale, plog);
+                else
+                    hipLaunchKernelGGL(gru_split_kernel<false>, ggrid, dim3(512), 0, s, gi,
+                                       reinterpret_cast<const uint4 *>(m->d_whhs[layer]), m->whh_oscale[layer],
+                                       m->d_bhn[layer], outs[layer], n_clips, Tp, static_cast<const uint4 *>(nullptr), 0.f,
+                                       static_cast<float *>(nullptr));
             else
                 hipLaunchKernelGGL(gru_kernel, ggrid, dim3(256), 0, s, gi,
                                    reinterpret_cast<const float4 *>(m->d_whh[layer]), m->d_bhn[layer], outs[layer],
@@ -1439,6 +1520,20 @@ int sedmi_crnn_create(sedmi_crnn **out, const sedmi_crnn_weights *w) {
         std::vector<float> wd(w->dense_w, w->dense_w + static_cast<size_t>(w->n_class) * HEAD_K);
         std::vector<float> bd(w->dense_b, w->dense_b + w->n_class);
         if ((rc = sedmi::upload(&m->d_wd, wd)) || (rc = sedmi::upload(&m->d_bd, bd))) return fail(rc);
+        if (w->n_class <= 16) {
+            // [dir][k-step of 16][plane][16 classes][16]: column n = class n (zero beyond n_class), rows = the
+            // direction's 128 inputs of the head
+            const int Sd = split_scale_exp(w->dense_w, static_cast<size_t>(w->n_class) * HEAD_K);
+            std::vector<uint16_t> wds;
+            for (int d = 0; d < 2; ++d) {
+                auto blk = pack_split(GRU_H / 16, 16, Sd, [&](int ks, int k16, int n) {
+                    return n < w->n_class ? w->dense_w[static_cast<size_t>(n) * HEAD_K + d * GRU_H + ks * 16 + k16] : 0.f;
+                });
+                wds.insert(wds.end(), blk.begin(), blk.end());
+            }
+            m->wd_oscale = std::ldexp(1.0f, -Sd);
+            if ((rc = sedmi::upload(&m->d_wds, wds))) return fail(rc);
+        }
     }
     *out = m;
     return SEDMI_OK;
@@ -1460,7 +1555,7 @@ int sedmi_crnn_destroy(sedmi_crnn *m) {
         (void)hipFree(m->d_whhs[l]);
         (void)hipFree(m->d_wih[l]); (void)hipFree(m->d_bi[l]); (void)hipFree(m->d_whh[l]); (void)hipFree(m->d_bhn[l]);
     }
-    (void)hipFree(m->d_wd); (void)hipFree(m->d_bd);
+    (void)hipFree(m->d_wd); (void)hipFree(m->d_bd); (void)hipFree(m->d_wds);
     delete m;
     return SEDMI_OK;
 }
@@ -1542,6 +1637,16 @@ int sedmi_crnn_forward_f32(const sedmi_crnn *m, const float *feats, int64_t n_cl
     SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = run_cnn(m, feats, n_clips, static_cast<int>(T), sc.seq, sc.actA, sc.actB, s))) return rc;
+    if (m->precision == SEDMI_PRECISION_SPLIT_F16 && m->d_wds != nullptr && head_fused_wanted()) {
+        // the head rides in layer 1's recurrence: partial logits go where rec1 would have gone
+        if ((rc = run_gru(m, sc.seq, n_clips, Tp, sc.gi, sc.rec0, sc.rec1, s, sc.rec1))) return rc;
+        const long rows = n_clips * Tp;
+        sedmi::ProfileScope prof("head_combine", s, 0.0, 4.0 * rows * (32.0 + m->n_class));
+        const unsigned grid = static_cast<unsigned>(std::min<long>(sedmi::ceil_div(rows * m->n_class, 256), 8L * m->num_cus));
+        hipLaunchKernelGGL(head_combine_kernel, dim3(grid), dim3(256), 0, s, sc.rec1, m->d_bd, probs, rows, m->n_class);
+        SEDMI_CHECK_LAUNCH();
+        return SEDMI_OK;
+    }
     if ((rc = run_gru(m, sc.seq, n_clips, Tp, sc.gi, sc.rec0, sc.rec1, s))) return rc;
     return sedmi_crnn_head_f32(m, sc.rec1, n_clips * Tp, probs, stream);
 }

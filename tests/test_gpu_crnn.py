@@ -45,7 +45,9 @@ def test_stages_match_reference_golden(golden_dir, fname, seed, ncls, precision)
     assert np.abs(rec.cpu().numpy() - g["gru_out"]).max() < 1e-4
     assert np.abs(probs.cpu().numpy() - g["probs"]).max() < PROB_TOL
     full = m(x)
-    assert torch.equal(full, probs)
+    # the staged head is the float32 kernel; inside the full forward (default precision, <= 16 classes) the head's
+    # products ride in the last GRU layer in split-f16 arithmetic
+    assert torch.equal(full, probs) if precision == "f32" else (full - probs).abs().max() < 1e-6
     assert np.abs(full.cpu().numpy() - g["probs"]).max() < 1e-4     # well inside the 1e-3 budget
 
 
