@@ -112,6 +112,22 @@ def test_gru_layer0_fused_and_separate_kernels_agree(golden_dir, monkeypatch):
     assert np.isfinite(outs["1", "big"]).all()
 
 
+@pytest.mark.parametrize("ncls", [1, 10, 16])
+def test_head_inside_the_last_gru_layer_agrees_with_the_head_kernel(ncls, monkeypatch):
+    """With at most 16 classes the full forward forms the head's products inside
+    layer 1's recurrence; SEDMI_HEAD_FUSED=0 runs the separate head kernel."""
+    m, sd = _model(4, ncls)
+    rng = np.random.Generator(np.random.PCG64(ncls))
+    x = torch.from_numpy(rng.gamma(0.5, 2.0, (37, 61, 128)).astype(np.float32)).cuda()     # a partly filled workgroup
+    fused = m(x)
+    monkeypatch.setenv("SEDMI_HEAD_FUSED", "0")
+    separate = m(x)
+    assert fused.shape == separate.shape == (37, 30, ncls)
+    assert (fused - separate).abs().max() < 1e-6
+    want = ocrnn.crnn_forward(sd, x.cpu()).numpy()
+    assert np.abs(fused.cpu().numpy() - want).max() < PROB_TOL
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("B,T", [(1, 501), (5, 501), (33, 64), (70, 9), (3, 2), (2, 7501), (600, 250)])
 def test_forward_matches_oracle_on_ragged_shapes(B, T, precision):
