@@ -16,7 +16,10 @@ already resident in HBM.  `value` = clips / second, whole job (all ranks).
                     AST embeddings the reference trained it on; feature_extraction.py:23,57)
   transformer       ShakeTransformer + decode, same input
   basic             mel (64 bins) + BasicRCNN + decode from audio, 1024 clips per GPU
-  rcnn-long         ShakeRCNN on 4 one-minute recordings per GPU (6000 frames -> 1500 GRU steps each)
+  rcnn-long         ShakeRCNN on 4 one-minute recordings per GPU (6000 frames -> 1500 GRU steps each): the latency
+                    case, a handful of long recordings
+  rcnn-long-64      the same with 64 one-minute recordings per GPU: the throughput case (a recurrence step costs
+                    little more for 64 recordings than for 4)
   transformer-long  ShakeTransformer on 2 four-minute recordings per GPU (24000 frames -> 6000 tokens each)
 
 Clips are independent, so every rank runs the same per-GPU batch (weak scaling) and
@@ -55,7 +58,7 @@ PEAK_HBM_GBPS = 8000.0            # MI355X HBM3E peak
 CONFIGS = {
     # name: (clips per GPU, kind)
     "crnn": 4096, "frontend": 4096, "rcnn": 128, "transformer": 128, "basic": 1024, "rcnn-long": 4,
-    "transformer-long": 2,
+    "rcnn-long-64": 64, "transformer-long": 2,
 }
 
 
@@ -132,7 +135,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline_crnn(y_sample: np.ndarray, sd, with_model=True):
+def cpu_baseline_crnn(y_sample: np.ndarray, sd, with_model=True, norm_stats=None):
     """The oracle's mel -> CRNN -> decode on the host, three ways: batched as evaluate() batches
     (evaluation.py:12-24) on all threads, and clip by clip as the prediction loop runs it
     (training.py:345-348: batch 1) on all threads and on one thread.  Returns the dict, the
@@ -142,7 +145,13 @@ def cpu_baseline_crnn(y_sample: np.ndarray, sd, with_model=True):
     n = len(y_sample)
     threads = int(torch.get_num_threads())
     t0 = time.perf_counter()
-    feats = np.stack([omel.clip_feature(c, SR, N_FFT, 128, HOP, WIN) for c in y_sample])
+    if norm_stats is None:
+        feats = np.stack([omel.clip_feature(c, SR, N_FFT, 128, HOP, WIN) for c in y_sample])
+    else:       # --normalise: log-mel, then (x - mean) / std with the statistics the GPU step used
+        mean, std = (np.asarray(v, dtype=np.float32) for v in norm_stats)
+        feats = np.stack([omel.normalise(omel.power_to_db(omel.melspectrogram(c, SR, N_FFT, 128, HOP, WIN)), mean, std)
+                          for c in y_sample])
+        feats = feats.reshape(len(feats), feats.shape[2], feats.shape[1])          # feature_extraction.py:49-50
     t_mel = time.perf_counter() - t0
     if not with_model:
         return dict(value=n / t_mel, unit="clips/s", cores=1, kind="port", cpu=cpu_model_name(),
@@ -229,6 +238,34 @@ def launch_ranks(n):
     return rc
 
 
+# ------------------------------------------------------------------------------------------------ rank bookkeeping
+def device_identity(rank, local_rank):
+    """What tells this rank's GPU from every other rank's: host name + PCI address (+ the device UUID)."""
+    p = torch.cuda.get_device_properties(local_rank)
+    pci = f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(getattr(p, 'pci_bus_id', -1)):02x}:{int(getattr(p, 'pci_device_id', -1)):02x}"
+    return dict(rank=rank, local_rank=local_rank, host=socket.gethostname(), pci=pci, uuid=str(getattr(p, "uuid", "")),
+                name=p.name, cus=int(p.multi_processor_count))
+
+
+def check_ranks(identities, n_gpus, world_size):
+    """Refuses (SystemExit) a job whose ranks do not sit on n_gpus DIFFERENT devices: a line that says n_gpus = 8
+    must come from 8 ranks on 8 GPUs.  identities: one device_identity() dict per rank, as all-gathered."""
+    if world_size != n_gpus or len(identities) != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but the process group has {world_size} ranks and "
+                         f"{len(identities)} reported a device: refusing to print a line")
+    if sorted(i["rank"] for i in identities) != list(range(n_gpus)):
+        raise SystemExit(f"bench.py: ranks seen {sorted(i['rank'] for i in identities)} are not 0..{n_gpus - 1}")
+    seen = {}
+    for i in identities:
+        key = (i["host"], i["pci"], i["uuid"])
+        if key in seen:
+            raise SystemExit(f"bench.py: ranks {seen[key]} and {i['rank']} run on the same device {key}: refusing to "
+                             f"print a {n_gpus}-GPU line measured on fewer GPUs")
+        seen[key] = i["rank"]
+    return [dict(rank=i["rank"], host=i["host"], pci=i["pci"], uuid=i["uuid"], name=i["name"], cus=i["cus"])
+            for i in sorted(identities, key=lambda i: i["rank"])]
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -245,7 +282,14 @@ def main():
                     help="crnn config: skip the extra exact-float32 pass behind the timed region (value_f32_exact)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: leave the all-gather of the frame predictions out of the step")
+    ap.add_argument("--normalise", action="store_true",
+                    help="crnn config: log-mel + mean/std normalisation with the statistics of the step's "
+                         "clips (the stages the reference does not have; off = the reference's features).  Every "
+                         "step then runs mel -> float64 statistics -> [N > 1: all-reduce over RCCL] -> normalise -> "
+                         "model -> decode")
     args = ap.parse_args()
+    if args.normalise and args.config != "crnn":
+        raise SystemExit("bench.py: --normalise applies to the crnn config only")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
@@ -260,10 +304,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        identities = [None] * world
+        dist.all_gather_object(identities, device_identity(rank, local_rank))
+        ranks_seen = check_ranks(identities, args.gpus, dist.get_world_size())     # every rank exits on a bad layout
 
     from sound_event_detection_amd import _lib, feature_extraction as fe
     from sound_event_detection_amd.pipeline import SedPipeline
@@ -276,15 +324,19 @@ def main():
     frames = args.frames
     dtype = "f32"
     model = sd = x = y = pipe = None
+    norm_kw = dict(log=True, normalise=True, group=True if world > 1 else None) if args.normalise else {}
     if kind in ("crnn", "frontend"):
         y = make_clips(clips, rank, device)
         model, sd = make_crnn(device)
         if args.precision:
             model.conv_precision = args.precision
-        pipe = SedPipeline(model, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN)
+        pipe = SedPipeline(model, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN, **norm_kw)
         shape = f"{clips} synthetic 10 s 16 kHz clips per GPU resident in HBM (n_fft 2048, win 640, hop 320, 128 mels"
         if kind == "crnn":
             workload = f"mel frontend + DCASE-baseline CRNN + threshold/run-length decode, {shape}, {N_CLS} classes)"
+            if args.normalise:
+                workload += ("; with log-mel + per-bin mean/std normalisation from the step's own clips"
+                             + (f" summed over the {world} ranks (all-reduce)" if world > 1 else ""))
             if model.conv_precision == "split_f16":
                 dtype = "f32 (contractions as split-f16 x3 on the f16 matrix cores, f32 accumulate)"
             step_fn = lambda: pipe.run(y)                                            # noqa: E731
@@ -301,7 +353,8 @@ def main():
         dtype = "f32 (3x3 convs and GRU input projection as split-f16 x3, f32 accumulate)"
         step_fn = lambda: pipe.run(y)                                                # noqa: E731
     else:
-        frames = frames or {"rcnn": 1000, "transformer": 1000, "rcnn-long": 6000, "transformer-long": 24000}[cfg]
+        frames = frames or {"rcnn": 1000, "transformer": 1000, "rcnn-long": 6000, "rcnn-long-64": 6000,
+                            "transformer-long": 24000}[cfg]
         x = make_feats(clips, frames, rank, device)
         model, sd = make_other(kind, device)
         pipe = SedPipeline(model, sr=SR, n_fft=N_FFT, hop_length=160, win_length=WIN)
@@ -313,6 +366,11 @@ def main():
         step_fn = lambda: pipe.run_features(x, alphas=alphas)                        # noqa: E731
 
     gather = world > 1 and not args.no_gather and kind != "frontend"
+    collectives = []
+    if world > 1 and args.normalise:
+        collectives.append(dict(name="all_reduce(sum) of the float64 mel statistics (2 * n_mels + 1 doubles)",
+                                backend="nccl (RCCL)", bytes_per_rank_per_step=8 * (2 * 128 + 1), calls_per_step=1,
+                                blocking=True))
     snap, gathered, works, counter = [None, None], [None, None], [None, None], [0]
 
     def step():
@@ -326,6 +384,9 @@ def main():
             if snap[i] is None:
                 snap[i] = torch.empty_like(p)
                 gathered[i] = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device=device)
+                if i == 0:
+                    collectives.append(dict(name="all_gather of the float32 frame predictions", backend="nccl (RCCL)",
+                                            bytes_per_rank_per_step=p.numel() * 4, calls_per_step=1, blocking=False))
             if works[i] is not None:
                 works[i].wait()
             snap[i].copy_(p)
@@ -354,9 +415,15 @@ def main():
     _lib.profile_enable(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    rank_ms = [1e3 * elapsed / steps]
     if dist is not None:
+        every = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, t)
+        rank_ms = [1e3 * float(v) / steps for v in every.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if pipe is not None and "n_events" in b:
+        pipe.check(b)               # a kernel that reported a failed run makes this raise: no line from NaN logits
     n_events = int(b["n_events"].item()) if "n_events" in b else None
 
     if rank == 0:
@@ -424,7 +491,8 @@ def main():
             if n_cpu > 0:
                 from oracle import acceptance as oacc
                 ns = min(n_cpu, clips)
-                cpu, cpu_probs, cpu_events = cpu_baseline_crnn(y[:ns].cpu().numpy(), sd)
+                stats = (b["mel_mean"].cpu().numpy(), b["mel_std"].cpu().numpy()) if args.normalise else None
+                cpu, cpu_probs, cpu_events = cpu_baseline_crnn(y[:ns].cpu().numpy(), sd, norm_stats=stats)
                 gpu_probs = b["probs"][:ns].cpu().numpy()
                 cpu["max_abs_prob_diff_vs_gpu"] = float(np.abs(gpu_probs - cpu_probs).max())
                 n_diff, n_bad, near = oacc.frame_differences(cpu_probs.reshape(-1, N_CLS), gpu_probs.reshape(-1, N_CLS),
@@ -489,6 +557,13 @@ def main():
                        "parallelism": f"clip-sharded x{world}",
                        "all_gather": "float32 frame predictions, asynchronous, every step" if gather else "none",
                        "events_last_step": n_events},
+            # what proves the line: the process group's size, each rank's device (all different, or no line is
+            # printed), each rank's own time per step (value uses the slowest), the collectives a step ran
+            "world_size": world if dist is None else dist.get_world_size(),
+            "ranks_seen": ranks_seen if ranks_seen is not None else [check_ranks(
+                [device_identity(0, local_rank)], 1, 1)[0]],
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(v, 3) for v in rank_ms]},
+            "collectives": collectives,
             **extra,
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -37,6 +37,7 @@ extern "C" {
 #define SEDMI_EHIP         -2   /* a HIP runtime call failed                 */
 #define SEDMI_ENOMEM       -3   /* workspace or capacity too small           */
 #define SEDMI_ENODEV       -4   /* no usable gfx950 device                   */
+#define SEDMI_ERECURRENCE  -5   /* sedmi_shake_rcnn_check: the single-launch recurrence gave up, outputs invalid */
 
 /* Library version (major*10000 + minor*100 + patch). */
 int sedmi_version(void);
@@ -94,11 +95,22 @@ int sedmi_melspec_i16(const sedmi_mel_plan *plan, const int16_t *y, int64_t n_cl
 /* Per-mel-bin sum and sum of squares over all clips and frames of a
  * [n_clips, n_mels, T] array, accumulated in float64 into device buffers
  * sum[n_mels], sumsq[n_mels] (ADDED to their current contents, so that ranks
- * can all-reduce them).  Supports the optional normalisation stage; the
+ * can all-reduce them).  Fixed summation order, no atomics: the same array
+ * gives the same sums bit for bit on every call.  Supports the optional normalisation stage; the
  * reference has no counterpart (its --normalize flag is never read:
  * training.py:91-94). */
 int sedmi_mel_stats_f64(const float *mel, int64_t n_clips, int n_mels, int64_t T,
                         double *sum, double *sumsq, void *stream);
+
+/* The optional stages applied IN PLACE to a [n_clips, n_mels, T] array that holds
+ * the power mel spectrogram (or, with SEDMI_MEL_NORMALISE alone, its log): the
+ * second pass of a dataset-level normalisation, whose mean and standard
+ * deviation are only known once every clip's statistics have been summed
+ * (sedmi_mel_stats_f64, all-reduced across ranks).  Same expressions, hence the
+ * same bits, as sedmi_melspec_f32 with these flags.  No counterpart in the
+ * reference (training.py:91-94: --normalize is parsed and never read). */
+int sedmi_mel_apply_f32(float *mel, int64_t n_clips, int n_mels, int64_t T, int flags,
+                        const float *mean, const float *istd, void *stream);
 
 /* ------------------------------------------------------------------------
  * Baseline CRNN, eval-mode forward.
@@ -238,6 +250,31 @@ size_t sedmi_shake_rcnn_workspace_bytes(const sedmi_shake_rcnn *model, int64_t n
 int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *model, const float *feats, int64_t n_clips,
                                  int64_t T, const float *alphas, float *logits,
                                  void *ws, size_t ws_bytes, void *stream);
+
+/* How the H = 1024 recurrence of sedmi_shake_rcnn_forward_f32 runs.
+ *   SEDMI_RECURRENCE_AUTO      up to 192 clips per call: ONE launch for all steps, W_hh resident in the registers
+ *                              of 128 (or, from 33 clips, 256) workgroups that exchange h through device memory
+ *                              every step; beyond that, one launch per step.  The single launch needs all its
+ *                              workgroups resident at the same time, one per compute unit: the GPU must not be
+ *                              shared with other kernels (another stream, another process) while it runs, and no
+ *                              compute unit may be masked off.  A workgroup that waits for a neighbour that never
+ *                              arrives gives up after a bounded number of polls (seconds), the kernel drains, the
+ *                              logits of that forward come out as NaN and sedmi_shake_rcnn_check reports it.
+ *   SEDMI_RECURRENCE_PER_STEP  always one launch per step (no residency requirement; 1.7-2x slower for few,
+ *                              long recordings).
+ * The default is SEDMI_RECURRENCE_AUTO.  No counterpart in the reference (nn.GRU at models.py:114,136). */
+#define SEDMI_RECURRENCE_AUTO      0
+#define SEDMI_RECURRENCE_PER_STEP  1
+int sedmi_shake_rcnn_set_recurrence(sedmi_shake_rcnn *model, int mode);
+
+/* Waits for `stream` (it synchronises) and reports whether the recurrence of the
+ * sedmi_shake_rcnn_forward_f32 call that last used workspace `ws` (same n_clips, T)
+ * ran to completion: SEDMI_OK, or SEDMI_ERECURRENCE when a workgroup of the
+ * single-launch recurrence gave up (the logits of that call are NaN; nothing else
+ * is affected).  Callers that must never act on NaN logits call it before they
+ * read the logits. */
+int sedmi_shake_rcnn_check(const sedmi_shake_rcnn *model, const void *ws, size_t ws_bytes,
+                           int64_t n_clips, int64_t T, void *stream);
 
 /* Stage-level entry point for parity tests: the three ShakeCNNBlocks followed
  * by transpose(1,2) + flatten (models.py:127-134): feats -> seq [n_clips, T/4, 6144]

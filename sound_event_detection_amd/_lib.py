@@ -16,10 +16,18 @@ SEDMI_MEL_NORMALISE = 2
 CRNN_LAYERS = 7
 PRECISION_F32 = 0
 PRECISION_SPLIT_F16 = 1
+SEDMI_ERECURRENCE = -5
+RECURRENCE_AUTO = 0
+RECURRENCE_PER_STEP = 1
 
 
 class SedmiError(RuntimeError):
     pass
+
+
+class SedmiRecurrenceError(SedmiError):
+    """The single-launch GRU recurrence of a ShakeRCNN forward gave up (SEDMI_ERECURRENCE): that forward's
+    logits are NaN."""
 
 
 class CrnnWeights(C.Structure):
@@ -92,6 +100,7 @@ SIGNATURES = {
     "sedmi_melspec_f32": (_I, [_VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "sedmi_melspec_i16": (_I, [_VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "sedmi_mel_stats_f64": (_I, [_VP, _I64, _I, _I64, _VP, _VP, _VP]),
+    "sedmi_mel_apply_f32": (_I, [_VP, _I64, _I, _I64, _I, _VP, _VP, _VP]),
     "sedmi_crnn_create": (_I, [C.POINTER(_VP), C.POINTER(CrnnWeights)]),
     "sedmi_crnn_destroy": (_I, [_VP]),
     "sedmi_crnn_set_precision": (_I, [_VP, _I]),
@@ -105,6 +114,8 @@ SIGNATURES = {
     "sedmi_shake_rcnn_destroy": (_I, [_VP]),
     "sedmi_shake_rcnn_workspace_bytes": (_SZ, [_VP, _I64, _I64]),
     "sedmi_shake_rcnn_forward_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
+    "sedmi_shake_rcnn_set_recurrence": (_I, [_VP, _I]),
+    "sedmi_shake_rcnn_check": (_I, [_VP, _VP, _SZ, _I64, _I64, _VP]),
     "sedmi_shake_cnn_f32": (_I, [_VP, _VP, _I64, _I64, C.POINTER(_F), _VP, _VP, _SZ, _VP]),
     "sedmi_shake_transformer_create": (_I, [C.POINTER(_VP), C.POINTER(ShakeTransformerWeights)]),
     "sedmi_shake_transformer_destroy": (_I, [_VP]),
@@ -150,7 +161,8 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str = "") -> int:
     if rc < 0:
         msg = lib().sedmi_last_error().decode("utf-8", "replace")
-        raise SedmiError(f"{what or 'sedmi call'} failed ({rc}): {msg}")
+        cls = SedmiRecurrenceError if rc == SEDMI_ERECURRENCE else SedmiError
+        raise cls(f"{what or 'sedmi call'} failed ({rc}): {msg}")
     return rc
 
 

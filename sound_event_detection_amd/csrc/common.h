@@ -46,18 +46,27 @@ int upload(T **dev, const std::vector<T> &host) {
 
 // Optional per-launch timing (see sedmi_profile_enable in sedmi.h).
 bool profile_enabled();
-long profile_begin(const char *name, hipStream_t stream, double flops, double bytes);   // record index or -1
-void profile_end(long index, hipStream_t stream);
+struct ProfileTicket {
+    long index;                 // position of the record; -1: none
+    unsigned long generation;   // of the record list at the time the record was pushed
+};
+ProfileTicket profile_begin(const char *name, hipStream_t stream, double flops, double bytes);
+void profile_end(ProfileTicket ticket, hipStream_t stream);
 
 struct ProfileScope {
     hipStream_t stream;
-    long index;            // this scope's record; -1: profiling off or the events could not be created
+    ProfileTicket ticket;  // this scope's record; index -1: profiling off or the events could not be created
     ProfileScope(const char *name, hipStream_t s, double flops, double bytes)
-        : stream(s), index(profile_enabled() ? profile_begin(name, s, flops, bytes) : -1) {}
+        : stream(s), ticket(profile_enabled() ? profile_begin(name, s, flops, bytes) : ProfileTicket{-1, 0}) {}
     ~ProfileScope() {
-        if (index >= 0) profile_end(index, stream);
+        if (ticket.index >= 0) profile_end(ticket, stream);
     }
 };
+
+// Raises a kernel's dynamic-LDS ceiling (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes` on the
+// current device.  The attribute belongs to the loaded function, not to a launch: the runtime is asked once per
+// (kernel, device) and size, later calls are a table look-up.
+int set_max_dynamic_lds(const void *kernel, size_t bytes);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

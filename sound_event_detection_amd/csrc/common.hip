@@ -1,7 +1,9 @@
 // libsedmi: error reporting, version, device probe.
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace sedmi {
 
@@ -18,6 +20,19 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+int set_max_dynamic_lds(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;      // (kernel, device) -> ceiling already set
+    int device = 0;
+    SEDMI_CHECK_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[{kernel, device}];
+    if (have >= bytes && have > 0) return SEDMI_OK;
+    SEDMI_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    have = bytes;
+    return SEDMI_OK;
+}
+
 namespace {
 struct ProfileRecord {
     const char *name;
@@ -27,31 +42,34 @@ struct ProfileRecord {
 std::mutex g_prof_mutex;
 bool g_prof_on = false;
 std::vector<ProfileRecord> g_prof_records;
+unsigned long g_prof_generation = 0;      // bumped whenever g_prof_records is cleared
 }  // namespace
 
 bool profile_enabled() { return g_prof_on; }
 
-// Returns the index of the new record, or -1 if its events could not be created (nothing is recorded then,
-// and a half-created pair is destroyed).
-long profile_begin(const char *name, hipStream_t stream, double flops, double bytes) {
+// Returns the ticket of the new record; index -1 if its events could not be created (nothing is recorded
+// then, and a half-created pair is destroyed).
+ProfileTicket profile_begin(const char *name, hipStream_t stream, double flops, double bytes) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ProfileRecord r{name, flops, bytes, nullptr, nullptr};
-    if (hipEventCreate(&r.start) != hipSuccess) return -1;
+    if (hipEventCreate(&r.start) != hipSuccess) return {-1, g_prof_generation};
     if (hipEventCreate(&r.stop) != hipSuccess) {
         (void)hipEventDestroy(r.start);
-        return -1;
+        return {-1, g_prof_generation};
     }
     (void)hipEventRecord(r.start, stream);
     g_prof_records.push_back(r);
-    return static_cast<long>(g_prof_records.size()) - 1;
+    return {static_cast<long>(g_prof_records.size()) - 1, g_prof_generation};
 }
 
-// Records the stop event of record `index` (as returned by profile_begin); ignores -1 and records that a
-// collect / enable has dropped in between.
-void profile_end(long index, hipStream_t stream) {
+// Records the stop event of the ticket's record.  A ticket whose record a collect / enable has dropped in
+// between carries an older generation and is ignored, so that it can never stop a record pushed afterwards
+// that happens to sit at the same index.
+void profile_end(ProfileTicket ticket, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (index >= 0 && static_cast<size_t>(index) < g_prof_records.size())
-        (void)hipEventRecord(g_prof_records[static_cast<size_t>(index)].stop, stream);
+    if (ticket.index >= 0 && ticket.generation == g_prof_generation &&
+        static_cast<size_t>(ticket.index) < g_prof_records.size())
+        (void)hipEventRecord(g_prof_records[static_cast<size_t>(ticket.index)].stop, stream);
 }
 
 }  // namespace sedmi
@@ -65,6 +83,7 @@ int sedmi_profile_enable(int on) {
         (void)hipEventDestroy(r.stop);
     }
     sedmi::g_prof_records.clear();
+    ++sedmi::g_prof_generation;
     sedmi::g_prof_on = on != 0;
     return SEDMI_OK;
 }
@@ -92,6 +111,7 @@ int sedmi_profile_collect(sedmi_kernel_stat *out, int capacity) {
         out[k].bytes += r.bytes;
     }
     sedmi::g_prof_records.clear();
+    ++sedmi::g_prof_generation;
     return n;
 }
 

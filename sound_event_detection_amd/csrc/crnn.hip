@@ -1126,9 +1126,8 @@ int launch_conv(const sedmi_crnn *m, int layer, const float *x, float *y, long n
     const int tiles = static_cast<int>(sedmi::ceil_div(H, G::TH));
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
     auto kern = conv_mfma_kernel<CIN, COUT, W>;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    static const std::string name = "conv_mfma<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc_lds;
+    static const std::string name = "conv_mfma_kernel<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
                                     std::to_string(W) + ">";
     const double pos = static_cast<double>(n_clips) * H * W;
     sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
@@ -1146,9 +1145,8 @@ int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, 
     const int tiles = static_cast<int>(sedmi::ceil_div(H, G::TH));
     const size_t lds = G::LDS_BYTES;
     auto kern = conv_split_kernel<CIN, COUT, W, WAVES_M, MT, CCH>;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    static const std::string name = "conv_split<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc_lds;
+    static const std::string name = "conv_split_kernel<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
                                     std::to_string(W) + ">";
     const double pos = static_cast<double>(n_clips) * H * W;
     sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
@@ -1200,7 +1198,7 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         const unsigned grid0 = static_cast<unsigned>(sedmi::ceil_div(total0, 256));
         {
             const double pos = static_cast<double>(nc) * (2.0 * Tp) * 128;
-            sedmi::ProfileScope prof("conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
+            sedmi::ProfileScope prof(m->precision == SEDMI_PRECISION_SPLIT_F16 ? "conv0_split_kernel" : "conv0_kernel", s, pos * (2.0 * 9 * 16 + 2.0 * 16 * 16),
                                      4.0 * nc * (static_cast<double>(T) * 128 + Tp * 64.0 * 16));
             if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
                 const int tiles = static_cast<int>(sedmi::ceil_div(Tp, C0_TH));
@@ -1250,18 +1248,16 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
             hipStream_t s, float *plog = nullptr) {
     const long rows = n_clips * Tp;
     const size_t lds = sizeof(float) * 128 * 132;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(linear_kernel), lds)) return rc_lds;
     const float *in = seq;
     float *outs[2] = {rec0, rec1};
     for (int layer = 0; layer < 2; ++layer) {
         const int K = layer == 0 ? GRU_H : 2 * GRU_H;
         if (layer == 0 && m->precision == SEDMI_PRECISION_SPLIT_F16 && gru0_fused_wanted()) {
             // flops: projection + recurrence; bytes: the conv output in, h out
-            sedmi::ProfileScope prof("gru0_fused", s, 2.0 * rows * 6 * GRU_H * K + 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
+            sedmi::ProfileScope prof("gru0_fused_kernel", s, 2.0 * rows * 6 * GRU_H * K + 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
                                      4.0 * rows * (GRU_H + 2.0 * GRU_H));
-            SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru0_fused_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, GRU0_LDS_BYTES));
+            if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(gru0_fused_kernel), GRU0_LDS_BYTES)) return rc_lds;
             const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
             hipLaunchKernelGGL(gru0_fused_kernel, ggrid, dim3(512), GRU0_LDS_BYTES, s, in,
                                reinterpret_cast<const uint4 *>(m->d_wihs[0]), m->wih_oscale[0], m->d_bi[0],
@@ -1272,7 +1268,7 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
             continue;
         }
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
-            sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj_split<128>" : "gru_input_proj_split<256>", s,
+            sedmi::ProfileScope prof(layer == 0 ? "linear_split_kernel<768,128,2>" : "linear_split_kernel<768,256,4>", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
             // persistent workgroups: as many as fit on the chip at once (two per CU at K = 128, one at K = 256)
             const long row_tiles = sedmi::ceil_div(rows, 128);
@@ -1280,19 +1276,17 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
             const uint4 *wsp = reinterpret_cast<const uint4 *>(m->d_wihs[layer]);
             if (layer == 0) {
                 const size_t lds2 = 2 * 128 * (128 * 2 + 16);
-                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 128, 2>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+                if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(linear_split_kernel<768, 128, 2>), lds2)) return rc_lds;
                 hipLaunchKernelGGL((linear_split_kernel<768, 128, 2>), grid, dim3(256), lds2, s, in, wsp, m->d_bi[layer],
                                    m->wih_oscale[layer], gi, rows);
             } else {
                 const size_t lds2 = 2 * 128 * (256 * 2 + 16);
-                SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_split_kernel<768, 256, 4>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+                if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(linear_split_kernel<768, 256, 4>), lds2)) return rc_lds;
                 hipLaunchKernelGGL((linear_split_kernel<768, 256, 4>), grid, dim3(512), lds2, s, in, wsp, m->d_bi[layer],
                                    m->wih_oscale[layer], gi, rows);
             }
         } else {
-            sedmi::ProfileScope prof(layer == 0 ? "gru_input_proj<128>" : "gru_input_proj<256>", s,
+            sedmi::ProfileScope prof(layer == 0 ? "linear_kernel(K=128)" : "linear_kernel(K=256)", s,
                                      2.0 * rows * 6 * GRU_H * K, 4.0 * rows * (K + 6.0 * GRU_H));
             hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 128)), 6), dim3(256),
                                lds, s, in, reinterpret_cast<const float4 *>(m->d_wih[layer]), m->d_bi[layer], gi,
@@ -1300,7 +1294,9 @@ int run_gru(const sedmi_crnn *m, const float *seq, long n_clips, int Tp, float *
         }
         SEDMI_CHECK_LAUNCH();
         {
-            sedmi::ProfileScope prof("gru_kernel", s, 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
+            sedmi::ProfileScope prof(m->precision != SEDMI_PRECISION_SPLIT_F16 ? "gru_kernel"
+                                     : layer == 1 && plog             ? "gru_split_kernel<true>"
+                                                                      : "gru_split_kernel<false>", s, 2.0 * rows * 2 * 3 * GRU_H * GRU_H,
                                      4.0 * rows * (6.0 * GRU_H + 2.0 * GRU_H));
             const dim3 ggrid(static_cast<unsigned>(sedmi::ceil_div(n_clips, GRU_NB)), 2);
             if (m->precision == SEDMI_PRECISION_SPLIT_F16)
@@ -1605,7 +1601,7 @@ int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, f
     SEDMI_REQUIRE(m != nullptr && n_rows >= 0, "bad argument");
     if (n_rows == 0) return SEDMI_OK;
     SEDMI_REQUIRE(rec && probs, "null data pointer");
-    sedmi::ProfileScope prof("head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
+    sedmi::ProfileScope prof(m->n_class <= HEAD_MAX_SMALL ? "head_small_kernel" : "head_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * HEAD_K * m->n_class,
                              4.0 * n_rows * (HEAD_K + m->n_class));
     if (m->n_class <= HEAD_MAX_SMALL) {
         // persistent waves over 32-row tiles: two workgroups of four waves per CU
@@ -1617,8 +1613,7 @@ int sedmi_crnn_head_f32(const sedmi_crnn *m, const float *rec, int64_t n_rows, f
         return SEDMI_OK;
     }
     const size_t lds = sizeof(float) * HEAD_ROWS * (HEAD_K + 1);
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(head_kernel), lds)) return rc_lds;
     hipLaunchKernelGGL(head_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(n_rows, HEAD_ROWS))), dim3(256), lds,
                        static_cast<hipStream_t>(stream), rec, m->d_wd, m->d_bd, probs, static_cast<long>(n_rows),
                        m->n_class);
@@ -1641,7 +1636,7 @@ int sedmi_crnn_forward_f32(const sedmi_crnn *m, const float *feats, int64_t n_cl
         // the head rides in layer 1's recurrence: partial logits go where rec1 would have gone
         if ((rc = run_gru(m, sc.seq, n_clips, Tp, sc.gi, sc.rec0, sc.rec1, s, sc.rec1))) return rc;
         const long rows = n_clips * Tp;
-        sedmi::ProfileScope prof("head_combine", s, 0.0, 4.0 * rows * (32.0 + m->n_class));
+        sedmi::ProfileScope prof("head_combine_kernel", s, 0.0, 4.0 * rows * (32.0 + m->n_class));
         const unsigned grid = static_cast<unsigned>(std::min<long>(sedmi::ceil_div(rows * m->n_class, 256), 8L * m->num_cus));
         hipLaunchKernelGGL(head_combine_kernel, dim3(grid), dim3(256), 0, s, sc.rec1, m->d_bd, probs, rows, m->n_class);
         SEDMI_CHECK_LAUNCH();

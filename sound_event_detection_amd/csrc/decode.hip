@@ -241,19 +241,19 @@ static int decode_launch(const float *p, int64_t total_frames, int n_class, cons
     const long long *sc = reinterpret_cast<const long long *>(seg_cutoff);
     const double dbytes = 4.0 * total_frames * n_class;
     timed = timed && sedmi::profile_enabled();
-    long rec = -1;
-    if (timed) rec = sedmi::profile_begin("decode_count", s, 0.0, dbytes);
+    sedmi::ProfileTicket rec{-1, 0};
+    if (timed) rec = sedmi::profile_begin("decode_kernel<false>", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));
     if (timed) sedmi::profile_end(rec, s);
     SEDMI_CHECK_LAUNCH();
-    if (timed) rec = sedmi::profile_begin("decode_scan", s, 0.0, 12.0 * pairs);
+    if (timed) rec = sedmi::profile_begin("scan_kernel", s, 0.0, 12.0 * pairs);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, counts, pairs, offsets,
                        reinterpret_cast<long long *>(n_events));
     if (timed) sedmi::profile_end(rec, s);
     SEDMI_CHECK_LAUNCH();
-    if (timed) rec = sedmi::profile_begin("decode_write", s, 0.0, dbytes);
+    if (timed) rec = sedmi::profile_begin("decode_kernel<true>", s, 0.0, dbytes);
     hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(64 * kWavesPerBlock), 0, s, p, n_class, ss, sc,
                        static_cast<long>(n_seg), thr, apply_sigmoid, half, counts, offsets, ev_seg, ev_cls,
                        ev_on, ev_off, static_cast<long>(capacity));

@@ -510,34 +510,55 @@ size_t mel_lds_bytes(int n_mels, int nnz) {
     return sizeof(float2) * G::SCR * WAVES + sizeof(float) * ((nnz + 3) & ~3) + sizeof(int) * 5 * n_pairs;
 }
 
-// float64 -> per-bin statistics for the optional normalisation stage
-__global__ __launch_bounds__(256) void mel_stats_kernel(const float *mel, long n_clips, int n_mels, long T,
-                                                        double *sum, double *sumsq) {
-    // one workgroup per (mel bin, clip slab); lanes stride over frames
+// float64 -> per-bin statistics for the optional normalisation stage.  One workgroup per mel bin walks every
+// clip's row of that bin in a fixed order (thread (x, y): frames x, x + 64, ... of clips y, y + 16, ...) and
+// reduces through a fixed tree, so the result does not depend on scheduling: the same array gives the same
+// sums bit for bit on every run and every rank.
+__global__ __launch_bounds__(1024) void mel_stats_kernel(const float *mel, long n_clips, int n_mels, long T,
+                                                         double *sum, double *sumsq) {
     const int m = blockIdx.x;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     double s = 0.0, s2 = 0.0;
-    for (long c = blockIdx.y; c < n_clips; c += gridDim.y) {
+    for (long c = ty; c < n_clips; c += 16) {
         const float *row = mel + (c * n_mels + m) * T;
-        for (long t = threadIdx.x; t < T; t += blockDim.x) {
+        for (long t = tx; t < T; t += 64) {
             const double v = row[t];
             s += v;
             s2 += v * v;
         }
     }
-    __shared__ double sh[2][256];
+    __shared__ double sh[2][1024];
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = s2;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        atomicAdd(&sum[m], sh[0][0]);
-        atomicAdd(&sumsq[m], sh[1][0]);
+    if (threadIdx.x == 0) {           // the only writer of bin m in this launch
+        sum[m] += sh[0][0];
+        sumsq[m] += sh[1][0];
+    }
+}
+
+// The optional stages on an array that already holds the power mel spectrogram, in place, with the very
+// expressions mel_kernel uses when the flags ride along with the transform.
+__global__ __launch_bounds__(256) void mel_apply_kernel(float *mel, long n_rows, int n_mels, long T, int flags,
+                                                        const float *mean, const float *istd) {
+    for (long r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int m = static_cast<int>(r % n_mels);
+        const float mu = (flags & SEDMI_MEL_NORMALISE) ? mean[m] : 0.f;
+        const float is = (flags & SEDMI_MEL_NORMALISE) ? istd[m] : 1.f;
+        float *row = mel + r * T;
+        for (long t = threadIdx.x; t < T; t += blockDim.x) {
+            float v = row[t];
+            if (flags & SEDMI_MEL_LOG) v = 10.0f * log10f(fmaxf(v, 1e-10f));
+            if (flags & SEDMI_MEL_NORMALISE) v = (v - mu) * is;
+            row[t] = v;
+        }
     }
 }
 
@@ -720,8 +741,7 @@ static int launch_mel(const sedmi_mel_plan *p, MelArgs &a, long n_clips, hipStre
     const size_t lds = mel_lds_bytes<R1, WAVES>(p->n_mels, p->nnz);
     SEDMI_REQUIRE(lds <= 160 * 1024, "mel kernel needs %zu B of LDS (> 160 KiB): n_mels too large", lds);
     auto kern = mel_kernel<R1, WAVES, ROW0, NROW, I16>;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc_lds;
     const long per_cu = std::max<long>(1, std::min<long>(8, (160 * 1024) / static_cast<long>(lds)));
     const long grid = std::min<long>(a.total_tiles, per_cu * p->num_cus);
     const double frames = static_cast<double>(n_clips) * a.T;
@@ -779,9 +799,26 @@ int sedmi_mel_stats_f64(const float *mel, int64_t n_clips, int n_mels, int64_t T
     SEDMI_REQUIRE(n_clips >= 0 && n_mels > 0 && T >= 0, "bad shape");
     if (n_clips == 0 || T == 0) return SEDMI_OK;
     SEDMI_REQUIRE(mel && sum && sumsq, "null data pointer");
-    const unsigned slabs = static_cast<unsigned>(std::min<int64_t>(n_clips, 64));
-    hipLaunchKernelGGL(mel_stats_kernel, dim3(n_mels, slabs), dim3(256), 0,
+    sedmi::ProfileScope prof("mel_stats_kernel", static_cast<hipStream_t>(stream), 3.0 * n_clips * n_mels * T,
+                             4.0 * n_clips * n_mels * T);
+    hipLaunchKernelGGL(mel_stats_kernel, dim3(n_mels), dim3(1024), 0,
                        static_cast<hipStream_t>(stream), mel, n_clips, n_mels, T, sum, sumsq);
+    SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int sedmi_mel_apply_f32(float *mel, int64_t n_clips, int n_mels, int64_t T, int flags, const float *mean,
+                        const float *istd, void *stream) {
+    SEDMI_REQUIRE(n_clips >= 0 && n_mels > 0 && T >= 0, "bad shape");
+    SEDMI_REQUIRE((flags & ~(SEDMI_MEL_LOG | SEDMI_MEL_NORMALISE)) == 0, "unknown flags 0x%x", flags);
+    SEDMI_REQUIRE(!(flags & SEDMI_MEL_NORMALISE) || (mean && istd), "normalisation needs mean and istd");
+    if (n_clips == 0 || T == 0 || flags == 0) return SEDMI_OK;
+    SEDMI_REQUIRE(mel != nullptr, "null data pointer");
+    const long n_rows = static_cast<long>(n_clips) * n_mels;
+    const unsigned grid = static_cast<unsigned>(std::min<long>(n_rows, 256L * 32));
+    sedmi::ProfileScope prof("mel_apply_kernel", static_cast<hipStream_t>(stream), 2.0 * n_rows * T, 8.0 * n_rows * T);
+    hipLaunchKernelGGL(mel_apply_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), mel, n_rows,
+                       n_mels, T, flags, mean, istd);
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }

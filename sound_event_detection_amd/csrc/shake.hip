@@ -730,7 +730,7 @@ constexpr int GP_U = 16;                       // hidden units per workgroup
 constexpr int GP_WG = GB_H / GP_U;             // 64 workgroups per direction and clip set
 constexpr int GP_MAX_G = 3;                    // groups per workgroup (four 32-clip groups would spill registers)
 constexpr int GP_MAX_MT = 2;                   // 16-clip MFMA tiles per group
-constexpr unsigned GP_SPIN_LIMIT = 3000000u;   // ~ seconds
+constexpr unsigned GP_SPIN_LIMIT = 3000000u;   // polls a wave makes before it gives up (~ seconds); default of the spin_limit argument
 constexpr int GP_LDS_BYTES = 96 * 1024;        // more than half of a CU's LDS: never two workgroups on one CU
 constexpr int GP_STATUS_WORDS = 64;            // status word + padding in front of the flags
 
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
     float *__restrict__ out,            // [clip][T][2048]
     uint4 *hx,                          // exchange array (gp_hx_index)
     unsigned *sync_words,               // [GP_STATUS_WORDS] status, then flags [2 dir][n_groups][64]; zeroed before the launch
-    long n_clips, int T, int n_groups, int n_sets) {
+    long n_clips, int T, int n_groups, int n_sets, unsigned spin_limit) {
     constexpr int CLIPS = 16 * MT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *red = reinterpret_cast<float *>(smem);                       // [wave][gate][mt][clip 16][unit 16]
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(512) void gru_big_persistent_kernel(
                     while (true) {
                         const unsigned f = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(f >= static_cast<unsigned>(s))) break;
-                        if (++spins > GP_SPIN_LIMIT) {
+                        if (++spins > spin_limit) {
                             gave_up = true;
                             if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(512) void gru_big_tagged_kernel(
     float *__restrict__ out,
     uint4 *hx,                          // exchange array (gt_hx_index), every byte 0xFF before the launch
     unsigned *sync_words,               // [0]: status, zero before the launch
-    long n_clips, int T, int n_groups, int n_sets) {
+    long n_clips, int T, int n_groups, int n_sets, unsigned spin_limit) {
     constexpr int CLIPS = 16 * MT;
     constexpr int RED_FLOATS = 8 * 3 * MT * 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(512) void gru_big_tagged_kernel(
                         const unsigned pa = probe[0] & probe[1] & probe[2] & probe[3], po = probe[0] | probe[1] | probe[2] | probe[3];
                         const bool ok = want ? (pa & 0x00010000u) != 0u : (po & 0x00010000u) == 0u;
                         if (__all(ok)) break;
-                        if (++spins > GP_SPIN_LIMIT) {
+                        if (++spins > spin_limit) {
                             gave_up = true;
                             if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(512) void gru_big_tagged_kernel(
                             }
                     const bool ok = want ? (all_and & 0x00010000u) != 0u : (all_or & 0x00010000u) == 0u;
                     if (__all(ok) || gave_up) break;
-                    if (++spins > GP_SPIN_LIMIT) {
+                    if (++spins > spin_limit) {
                         gave_up = true;
                         if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
@@ -1636,6 +1636,7 @@ struct EncoderLayerDev {
 
 struct sedmi_shake_rcnn {
     int n_class = 0, num_cus = 0;
+    int recurrence = SEDMI_RECURRENCE_AUTO;
     ShakeCnnDev cnn;
     LinearDev wih;                       // both directions: N = 2 * 3072
     uint16_t *d_whh = nullptr;
@@ -1744,8 +1745,7 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
     const int tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
     if (4.0 * H * W * CIN >= 2147483648.0) return SEDMI_EINVAL;      // one clip's input is addressed with 32-bit offsets
     auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN>;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), G::LDS_BYTES)) return rc_lds;
     const double pos = static_cast<double>(n) * H * W;
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
                              pos * 4.0 * (CIN + (MODE == MODE_BIAS || MODE == MODE_POOL_W5 ? N : MODE == MODE_POOL_NCHW ? N / 4.0 : MODE == MODE_GLU ? N / 2.0
@@ -1799,8 +1799,7 @@ int launch_linear(const char *name, const LinearDev &L, const float *A, float *C
     if (L.K % KC || L.N % 128 || 4.0 * TM * std::max(L.K, L.N) >= 2147483648.0) return SEDMI_EINVAL;
     auto kern = gemm_split_kernel<MT, KC, DB>;
     const size_t lds = (DB ? 4 : 2) * TM * (KC * 2 + 16);
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc_lds;
     sedmi::ProfileScope prof(name, s, 2.0 * rows * L.N * static_cast<double>(L.K), 4.0 * rows * (L.N + static_cast<double>(L.K)));
     const unsigned m_tiles = static_cast<unsigned>(sedmi::ceil_div(rows, TM)), n_tiles = L.N / 128;
     hipLaunchKernelGGL(kern, dim3((m_tiles * n_tiles + 7) / 8 * 8), dim3(256), lds, s,
@@ -1815,6 +1814,17 @@ int launch_linear(const char *name, const LinearDev &L, const float *A, float *C
 bool gru_persistent_wanted() {
     const char *e = std::getenv("SEDMI_SHAKE_GRU_PERSISTENT");
     return e == nullptr || e[0] != '0';
+}
+
+// Polls a waiting wave of the persistent recurrence makes before it gives up and raises the status word.
+// SEDMI_SHAKE_GRU_SPIN_LIMIT overrides the default (tests set it to 0 to drive the give-up path: the first poll
+// that finds its producers not ready yet then ends the wait).
+unsigned gru_spin_limit() {
+    const char *e = std::getenv("SEDMI_SHAKE_GRU_SPIN_LIMIT");
+    if (e == nullptr || e[0] == '\0') return GP_SPIN_LIMIT;
+    char *end = nullptr;
+    const unsigned long v = std::strtoul(e, &end, 10);
+    return end == e ? GP_SPIN_LIMIT : static_cast<unsigned>(std::min<unsigned long>(v, 0xfffffff0ul));
 }
 
 // Which hand-off the persistent recurrence uses: separate flags (gru_big_persistent_kernel) or step tags inside
@@ -1833,21 +1843,19 @@ int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_group
                           hipStream_t s) {
     if (!gru_exchange_by_flags(G)) {
         auto kern = gru_big_tagged_kernel<G, MT>;
-        SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            GP_LDS_BYTES));
+        if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), GP_LDS_BYTES)) return rc_lds;
         SEDMI_CHECK_HIP(hipMemsetAsync(sc.hx, 0xff, static_cast<size_t>(gt_hx_index(MT, 2, 0, n_groups, 0, 0)) * 16, s));
         hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
                            reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words,
-                           n, T4, n_groups, n_sets);
+                           n, T4, n_groups, n_sets, gru_spin_limit());
         SEDMI_CHECK_LAUNCH();
         return SEDMI_OK;
     }
     auto kern = gru_big_persistent_kernel<G, MT>;
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        GP_LDS_BYTES));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), GP_LDS_BYTES)) return rc_lds;
     hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
                        reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words, n,
-                       T4, n_groups, n_sets);
+                       T4, n_groups, n_sets, gru_spin_limit());
     SEDMI_CHECK_LAUNCH();
     return SEDMI_OK;
 }
@@ -1864,7 +1872,8 @@ int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, c
     const int n_groups = static_cast<int>(sedmi::ceil_div(n, 16 * MT));
     const int n_sets = n_groups >= 2 && 2 * 2 * GP_WG <= m->num_cus ? 2 : 1;
     const int G = static_cast<int>(sedmi::ceil_div(n_groups, n_sets));
-    if (gru_persistent_wanted() && G <= GP_MAX_G && 2 * GP_WG * n_sets <= m->num_cus && T4 >= 2) {
+    if (m->recurrence == SEDMI_RECURRENCE_AUTO && gru_persistent_wanted() && G <= GP_MAX_G &&
+        2 * GP_WG * n_sets <= m->num_cus && T4 >= 2) {
         sedmi::ProfileScope prof("shake_gru_persistent", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
         if (MT == 1) return launch_gru_persistent<1, 1>(m, n, T4, n_groups, n_sets, sc, s);
         switch (G) {
@@ -1875,8 +1884,7 @@ int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, c
     }
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));
     const size_t lds = 4 * 2 * 32 * ((GB_H / 4) * 2 + 16);
-    SEDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_big_step_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(gru_big_step_kernel), lds)) return rc_lds;
     float *hp = sc.h0, *hn = sc.h1;
     sedmi::ProfileScope prof("shake_gru_steps", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
     for (int step = 0; step < T4; ++step) {
@@ -2173,6 +2181,34 @@ int sedmi_shake_rcnn_forward_f32(const sedmi_shake_rcnn *m, const float *feats, 
     hipLaunchKernelGGL((ln_head_kernel<2048, true>), dim3(static_cast<unsigned>(sedmi::ceil_div(rows, 4))), dim3(256), 0, s,
                        sc.rec, m->d_lw, m->d_lb, m->d_fw, m->d_fb, logits, rows, m->n_class, sc.sync_words);
     SEDMI_CHECK_LAUNCH();
+    return SEDMI_OK;
+}
+
+int sedmi_shake_rcnn_set_recurrence(sedmi_shake_rcnn *m, int mode) {
+    SEDMI_REQUIRE(m != nullptr, "model is null");
+    SEDMI_REQUIRE(mode == SEDMI_RECURRENCE_AUTO || mode == SEDMI_RECURRENCE_PER_STEP, "unknown recurrence mode %d", mode);
+    m->recurrence = mode;
+    return SEDMI_OK;
+}
+
+int sedmi_shake_rcnn_check(const sedmi_shake_rcnn *m, const void *ws, size_t ws_bytes, int64_t n, int64_t T, void *stream) {
+    int rc = shake_check(m, n, T);
+    if (rc) return rc;
+    if (n == 0 || T < 4) return SEDMI_OK;
+    SEDMI_REQUIRE(ws != nullptr, "null pointer");
+    ShakeScratch sc = carve_shake(const_cast<void *>(ws), n, T, SHAKE_RCNN);
+    SEDMI_REQUIRE(ws_bytes >= sc.bytes, "workspace too small: need %zu bytes, got %zu", sc.bytes, ws_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned status = 0;
+    SEDMI_CHECK_HIP(hipMemcpyAsync(&status, sc.sync_words, sizeof(status), hipMemcpyDeviceToHost, s));
+    SEDMI_CHECK_HIP(hipStreamSynchronize(s));
+    if (status != 0)
+        return sedmi::set_error(SEDMI_ERECURRENCE,
+                                "the single-launch GRU recurrence gave up waiting for a neighbouring workgroup (its 128 or 256 "
+                                "workgroups must all be resident at once, one per compute unit: the GPU was shared with "
+                                "other work, or compute units are masked); the logits of that forward are NaN. Run the "
+                                "forward again with sedmi_shake_rcnn_set_recurrence(model, SEDMI_RECURRENCE_PER_STEP) "
+                                "or on an otherwise idle GPU");
     return SEDMI_OK;
 }
 

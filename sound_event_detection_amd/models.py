@@ -13,6 +13,13 @@ The module tree only owns tensors; ``forward`` packs them once into a
 ``sedmi_shake_rcnn`` / ``sedmi_shake_transformer`` handle and runs the HIP
 kernels of csrc/shake.hip through the C ABI.  Inference only, CUDA (ROCm) tensors only, no CPU path.
 
+ShakeRCNN's recurrence: up to 192 clips per call it runs as ONE kernel launch whose 128 / 256 workgroups must
+all be resident at once (one per compute unit), i.e. on a GPU that runs nothing else meanwhile.  If that
+does not hold, the kernel gives up after a bounded wait and the forward's logits are NaN; ``forward`` notices
+(it waits for the stream and reads the kernel's status word), switches the model to one launch per step
+(``model.recurrence = "per_step"``, 1.7-2x slower for few long recordings) and runs again;
+``SedPipeline`` raises ``SedmiRecurrenceError`` from ``events()`` / ``check()`` instead of decoding NaNs.
+
 ShakeShake mixing weight: in eval mode the reference draws ``a = torch.rand(1)``
 per block on every forward (:88-91).  ``forward`` does the same (CPU generator,
 three draws in block order, so the same ``torch.manual_seed`` gives the same
@@ -220,6 +227,35 @@ class ShakeRCNN(_ShakeBase):
         self.sigmoid = nn.Sigmoid()
         self.softmax = nn.Softmax(dim=-1)
         self.relu = nn.LeakyReLU()
+        self._recurrence = "auto"
+
+    @property
+    def recurrence(self):
+        """"auto": the single-launch recurrence whenever the batch fits it; "per_step": always one launch per
+        step (no requirement that the GPU be otherwise idle)."""
+        return self._recurrence
+
+    @recurrence.setter
+    def recurrence(self, mode):
+        if mode not in ("auto", "per_step"):
+            raise ValueError('recurrence must be "auto" or "per_step"')
+        self._recurrence = mode
+        if self._handle is not None:
+            self._apply_recurrence(self._handle)
+
+    def _apply_recurrence(self, handle):
+        mode = _lib.RECURRENCE_AUTO if self._recurrence == "auto" else _lib.RECURRENCE_PER_STEP
+        _lib.check(_lib.lib().sedmi_shake_rcnn_set_recurrence(handle, mode), "sedmi_shake_rcnn_set_recurrence")
+
+    def _check_run(self, handle, ws, ws_bytes, B, T, stream):
+        """Waits for ``stream`` and raises SedmiRecurrenceError if the recurrence of the forward that used ``ws``
+        gave up; the model is then switched to one launch per step so that the next forward cannot."""
+        try:
+            _lib.check(_lib.lib().sedmi_shake_rcnn_check(handle, _lib.ptr(ws), ws_bytes, B, T, stream),
+                       "sedmi_shake_rcnn_check")
+        except _lib.SedmiRecurrenceError:
+            self.recurrence = "per_step"
+            raise
 
     def _get_handle(self, device):
         sig = (device.index, self._signature())
@@ -245,6 +281,7 @@ class ShakeRCNN(_ShakeBase):
             _lib.check(_lib.lib().sedmi_shake_rcnn_create(C.byref(handle), C.byref(w)), "sedmi_shake_rcnn_create")
         self._handle, self._handle_sig = handle, sig
         self._handle_fin = weakref.finalize(self, _lib.lib().sedmi_shake_rcnn_destroy, handle)
+        self._apply_recurrence(handle)
         return handle
 
     def _workspace_bytes(self, handle, B, T):
@@ -266,9 +303,19 @@ class ShakeRCNN(_ShakeBase):
         ws_bytes = lib.sedmi_shake_rcnn_workspace_bytes(handle, B, T)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.sedmi_shake_rcnn_forward_f32(handle, _lib.ptr(x), B, T, al, _lib.ptr(logits), _lib.ptr(ws),
-                                                        ws_bytes, _lib.stream_ptr(x.device)),
-                       "sedmi_shake_rcnn_forward_f32")
+            st = _lib.stream_ptr(x.device)
+            for attempt in (0, 1):
+                _lib.check(lib.sedmi_shake_rcnn_forward_f32(handle, _lib.ptr(x), B, T, al, _lib.ptr(logits),
+                                                            _lib.ptr(ws), ws_bytes, st), "sedmi_shake_rcnn_forward_f32")
+                try:
+                    self._check_run(handle, ws, ws_bytes, B, T, st)       # waits for the stream
+                    break
+                except _lib.SedmiRecurrenceError as e:
+                    if attempt:
+                        raise
+                    import warnings
+                    warnings.warn(f"{e}; running this forward again with one launch per step "
+                                  f"(model.recurrence is now \"per_step\")", RuntimeWarning)
         return logits
 
     def forward_cnn(self, x, alphas=None):

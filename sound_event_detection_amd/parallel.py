@@ -66,16 +66,27 @@ def all_gather_probs(local: torch.Tensor, n_total: int, group=None) -> torch.Ten
     return out[:n_total]
 
 
+MEL_STD_FLOOR = 1e-12      # a bin that never varies (all-zero audio) is divided by this, not by zero
+
+
+def mel_stats_to_mean_std(s: torch.Tensor, s2: torch.Tensor, count):
+    """float64 (sum, sum of squares) per mel bin and the number of values per bin -> (mean, std), float64,
+    population variance (the mean of squares minus the squared mean, clamped at zero)."""
+    # a tensor divisor: dividing a device tensor by a Python number multiplies by its reciprocal instead, which
+    # differs from the all-reduced path's tensor / tensor division in the last bit
+    count = torch.as_tensor(count, dtype=torch.float64, device=s.device)
+    mean = s / count
+    var = (s2 / count - mean * mean).clamp_min(0.0)
+    return mean, var.sqrt().clamp_min(MEL_STD_FLOOR)
+
+
 def all_reduce_mel_stats(s: torch.Tensor, s2: torch.Tensor, count: float, group=None):
     """(sum, sum of squares, count) per mel bin, float64 -> (mean, std) of the
     whole dataset on every rank: one all-reduce of 2 * n_mels + 1 doubles."""
     buf = torch.cat([s.double(), s2.double(), torch.tensor([count], dtype=torch.float64, device=s.device)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     m = s.numel()
-    n = buf[-1]
-    mean = buf[:m] / n
-    var = (buf[m:2 * m] / n - mean * mean).clamp_min(0.0)
-    return mean, var.sqrt()
+    return mel_stats_to_mean_std(buf[:m], buf[m:2 * m], buf[-1])
 
 
 def predict_files_sharded(model, test_files, dataset_location, dataset, clip_length, *args, group=None,
@@ -86,12 +97,17 @@ def predict_files_sharded(model, test_files, dataset_location, dataset, clip_len
     id2cls, block_length, ...).  Recordings stay whole (a recording's clips are decoded as one frame sequence,
     training.py:350), ranks get contiguous runs of files balanced by clip count, and every rank returns the
     complete event list in the order of ``test_files`` -- what the single-process call returns.
-    ``return_probs`` is not supported here (frame predictions stay on the rank that made them)."""
+    ``return_probs`` is not supported here (frame predictions stay on the rank that made them).
+    ``normalise=True`` without ``mean`` / ``std`` normalises with the statistics of ALL files: each rank sums its
+    share and ``all_reduce_mel_stats`` adds the shares (every rank must make the call, files or not)."""
     import numpy as np
 
     from . import feature_extraction as fe
     if kwargs.get("return_probs"):
         raise ValueError("predict_files_sharded returns events only")
+    if kwargs.get("normalise") and kwargs.get("mean") is None:
+        # statistics of the whole file list, not of this rank's share: every rank adds its sums to the others'
+        kwargs.setdefault("stats_group", True if group is None else group)
     if predict_fn is None:
         from .predict import predict_files as predict_fn
     world, rank = dist.get_world_size(group), dist.get_rank(group)

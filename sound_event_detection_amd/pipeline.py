@@ -16,6 +16,20 @@ then applies the sigmoid, ``apply_sigmoid = (model != 'Baseline')``,
 training.py:358).  The mel width follows the model: 128 for the CRNN,
 ``frequency_dim`` for BasicRCNN, 768 for the Shake models (the width their GRU /
 ``fc1`` input of 6144 = 64 * 768 / 8 dictates, models.py:114,194).
+
+Two feature stages the reference does not have (its ``--normalize`` flag is
+parsed and never read, training.py:91-94) can be switched on; both default to
+off, which is the reference's behaviour:
+
+``log=True``        10 * log10(max(S, 1e-10)) on the mel spectrogram;
+``normalise=True``  per-mel-bin (x - mean) / std.  With ``mean`` / ``std`` given
+                    (dataset-level statistics computed beforehand) the stage
+                    rides in the mel kernel.  Without them the statistics are
+                    those of the clips of the call itself, over all ranks of
+                    ``group`` when one is given: mel pass -> float64 sums per bin
+                    (``sedmi_mel_stats_f64``) -> one all-reduce of 2 * n_mels + 1
+                    doubles (``parallel.all_reduce_mel_stats``) -> in-place
+                    normalisation (``sedmi_mel_apply_f32``) -> model.
 """
 from __future__ import annotations
 
@@ -28,12 +42,16 @@ from . import feature_extraction as fe
 
 class SedPipeline:
     def __init__(self, model, *, sr=16000, n_fft=2048, n_mels=None, hop_length=320, win_length=640,
-                 block_length=40, decision_threshold=0.5, apply_sigmoid=None, median_window=1):
+                 block_length=40, decision_threshold=0.5, apply_sigmoid=None, median_window=1,
+                 log=False, normalise=False, mean=None, std=None, group=None):
         """``model``: one of the package's model classes in eval mode on a CUDA
         device.  ``n_mels`` defaults to the model's feature width and must equal
         it.  ``apply_sigmoid`` defaults to what training.py:358 passes: False
         for the baseline CRNN (it already returns probabilities), True for the
-        models that return logits."""
+        models that return logits.  ``log`` / ``normalise`` / ``mean`` / ``std`` /
+        ``group``: the optional feature stages described in the module docstring
+        (``group``: a ``torch.distributed`` process group, or True for the
+        default group; None = this process's clips only)."""
         for attr in ("returns_logits", "time_pooling", "feature_width", "n_outputs", "_forward_into", "_get_handle"):
             if not hasattr(model, attr):
                 raise TypeError(f"{type(model).__name__} is not one of this package's models (no {attr})")
@@ -47,6 +65,13 @@ class SedPipeline:
         self.thr = float(decision_threshold)
         self.apply_sigmoid = bool(model.returns_logits if apply_sigmoid is None else apply_sigmoid)
         self.median_window = int(median_window)
+        self.log, self.normalise = bool(log), bool(normalise)
+        if (mean is None) != (std is None):
+            raise ValueError("mean and std must be given together")
+        if mean is not None and not self.normalise:
+            raise ValueError("mean / std are only used with normalise=True")
+        self.mean, self.std, self.group = mean, std, group
+        self._fixed_stats = None        # (device, mean f32, 1/std f32) of user-supplied statistics
         self._buf = None
 
     # ---------------------------------------------------------------- buffers
@@ -86,6 +111,8 @@ class SedPipeline:
         if clips_per_recording is None:
             clips_per_recording = (1,) * B
         clips_per_recording = tuple(int(c) for c in clips_per_recording)
+        if any(c <= 0 for c in clips_per_recording):
+            raise ValueError("every recording must own at least one clip (clips_per_recording has an entry <= 0)")
         if sum(clips_per_recording) != B:
             raise ValueError("clips_per_recording must sum to the number of clips")
         n_seg = len(clips_per_recording)
@@ -127,7 +154,20 @@ class SedPipeline:
         res = dict(b)
         res["probs"] = out       # probabilities (CRNN) or logits (the other models): what the model returns
         res["n_seg"] = n_seg
+        # models whose kernels can report a failed run after the fact (ShakeRCNN's single-launch recurrence)
+        res["_check"] = (handle, B, T, dev) if hasattr(model, "_check_run") else None
         return res
+
+    def check(self, b):
+        """Waits for the run that produced ``b`` and raises if one of its kernels reported that it could not
+        finish (``SedmiRecurrenceError``: ShakeRCNN's single-launch recurrence gave up because the GPU was shared;
+        the run's predictions are NaN and its event list is empty -- never act on them).  ``events`` calls this;
+        callers that read ``b["probs"]`` themselves call it first."""
+        c = b.get("_check")
+        if c is not None:
+            handle, B, T, dev = c
+            with torch.cuda.device(dev):
+                self.model._check_run(handle, b["ws"], b["ws_bytes"], B, T, _lib.stream_ptr(dev))
 
     def run(self, y: torch.Tensor, clips_per_recording=None, cutoffs=None, alphas=None):
         """y: float32 (or int16 PCM, taken as sample / 32768) CUDA tensor [B, N] of equally long clips; consecutive clips
@@ -147,13 +187,48 @@ class SedPipeline:
         b = self._buffers(B, T, dev, True)
         mel = b["mel"][:B]
         entry = "sedmi_melspec_i16" if y.dtype == torch.int16 else "sedmi_melspec_f32"
+        lib = _lib.lib()
+        flags = _lib.SEDMI_MEL_LOG if self.log else 0
+        mean = istd = stats = None
+        if self.normalise and self.mean is not None:        # dataset-level statistics known beforehand: one pass
+            if self._fixed_stats is None or self._fixed_stats[0] != dev:
+                m32 = torch.as_tensor(self.mean).to(dev, torch.float32).contiguous()
+                i32 = (1.0 / torch.as_tensor(self.std).to(dev, torch.float64)).to(torch.float32).contiguous()
+                if m32.numel() != self.n_mels or i32.numel() != self.n_mels:
+                    raise ValueError(f"mean / std must have {self.n_mels} entries")
+                self._fixed_stats = (dev, m32, i32)
+            _, mean, istd = self._fixed_stats
+            flags |= _lib.SEDMI_MEL_NORMALISE
         with torch.cuda.device(dev):
-            _lib.check(getattr(_lib.lib(), entry)(plan.handle, _lib.ptr(y), B, N, 0, None, None, _lib.ptr(mel),
-                                                  _lib.stream_ptr(dev)), entry)
+            st = _lib.stream_ptr(dev)
+            _lib.check(getattr(lib, entry)(plan.handle, _lib.ptr(y), B, N, flags, _lib.ptr(mean), _lib.ptr(istd),
+                                           _lib.ptr(mel), st), entry)
+            if self.normalise and self.mean is None:        # statistics of this call's clips: two passes
+                stats = self._batch_statistics(mel, B, T, dev)
+                _lib.check(lib.sedmi_mel_apply_f32(_lib.ptr(mel), B, self.n_mels, T, _lib.SEDMI_MEL_NORMALISE,
+                                                   _lib.ptr(stats[2]), _lib.ptr(stats[3]), st), "sedmi_mel_apply_f32")
         # the [B, n_mels, T] bytes are the [B, T, n_mels] feature (feature_extraction.py:49-50)
         res = self._model_and_decode(b, _lib.ptr(mel), B, T, dev, clips_per_recording, cutoffs, alphas)
         res["mel"] = mel
+        if stats is not None:
+            res["mel_mean"], res["mel_std"] = stats[0], stats[1]        # float64 [n_mels], on the device
         return res
+
+    def _batch_statistics(self, mel, B, T, dev):
+        """float64 (mean, std) per mel bin of ``mel`` over the clips of every rank of ``self.group``, plus the
+        float32 (mean, 1 / std) the normalisation kernel reads.  Everything stays on the device; with a group
+        this is the path's one all-reduce (2 * n_mels + 1 doubles)."""
+        from . import parallel
+        M = self.n_mels
+        s = torch.zeros(2 * M, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().sedmi_mel_stats_f64(_lib.ptr(mel), B, M, T, _lib.ptr(s), _lib.ptr(s[M:]),
+                                                  _lib.stream_ptr(dev)), "sedmi_mel_stats_f64")
+        group = None if self.group is True else self.group
+        if self.group is not None:
+            mean, std = parallel.all_reduce_mel_stats(s[:M], s[M:], float(B * T), group=group)
+        else:
+            mean, std = parallel.mel_stats_to_mean_std(s[:M], s[M:], float(B * T))
+        return mean, std, mean.to(torch.float32), (1.0 / std).to(torch.float32)
 
     def run_features(self, feats: torch.Tensor, clips_per_recording=None, cutoffs=None, alphas=None):
         """The same from precomputed features [B, T, width] (float32, CUDA,
@@ -169,6 +244,7 @@ class SedPipeline:
     def events(self, b, id2cls, names):
         """Host-side event list of a finished run, in the reference's format:
         (name, onset_s, offset_s, class) with float64 times (evaluation.py:75-78)."""
+        self.check(b)
         n = int(b["n_events"].item())
         if n > b["cap_ev"]:
             raise _lib.SedmiError(f"{n} events exceed the event buffer's capacity {b['cap_ev']}")

@@ -28,3 +28,29 @@ def test_gpus_without_a_launcher_starts_that_many_ranks():
     # every rank gets as far as the device check and fails loudly there: there is no CPU fallback
     assert r.returncode != 0
     assert r.stderr.count("needs an MI355X") == 3 and r.stdout.strip() == ""
+
+
+def _ident(rank, pci, host="box", uuid=""):
+    return dict(rank=rank, local_rank=rank, host=host, pci=pci, uuid=uuid or pci, name="gpu", cus=256)
+
+
+def test_a_multi_gpu_line_needs_as_many_different_devices_as_ranks():
+    sys.path.insert(0, ROOT)
+    import bench
+    ok = bench.check_ranks([_ident(1, "0000:0b:00"), _ident(0, "0000:0a:00")], 2, 2)
+    assert [r["rank"] for r in ok] == [0, 1] and ok[0]["pci"] == "0000:0a:00"
+    # the same PCI address on another host is another device
+    assert len(bench.check_ranks([_ident(0, "0000:0a:00", "a"), _ident(1, "0000:0a:00", "b")], 2, 2)) == 2
+    with pytest.raises(SystemExit, match="same device"):
+        bench.check_ranks([_ident(0, "0000:0a:00"), _ident(1, "0000:0a:00")], 2, 2)
+    with pytest.raises(SystemExit, match="refusing to print"):
+        bench.check_ranks([_ident(0, "0000:0a:00")], 2, 1)              # world size differs from --gpus
+    with pytest.raises(SystemExit, match="refusing to print"):
+        bench.check_ranks([_ident(0, "0000:0a:00")], 2, 2)              # a rank did not report
+    with pytest.raises(SystemExit, match="are not 0..1"):
+        bench.check_ranks([_ident(0, "0000:0a:00"), _ident(0, "0000:0b:00")], 2, 2)
+
+
+def test_normalise_is_refused_for_configs_that_do_not_have_the_stage():
+    r = _run(["--config", "rcnn", "--normalise"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--normalise applies" in r.stderr and r.stdout.strip() == ""

@@ -159,3 +159,39 @@ def test_shake_rcnn_recurrence_in_one_launch_agrees_with_per_step_launches(n_cli
     np.testing.assert_allclose(per_step, want, rtol=0, atol=ATOL_LOGITS)
     np.testing.assert_allclose(got["flag"], per_step, rtol=0, atol=2e-4)
     np.testing.assert_allclose(got["tag"], got["flag"], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("exchange", ["tag", "flag"])
+def test_recurrence_that_gives_up_is_an_exception_never_nan_or_an_empty_event_list(monkeypatch, exchange):
+    """The single-launch recurrence needs all its workgroups resident at once; when a wave's bounded wait for a
+    neighbour runs out the kernel drains and the logits are NaN.  With the wait cut to zero polls
+    (SEDMI_SHAKE_GRU_SPIN_LIMIT=0: the first poll that finds a producer not ready gives up) the failure is driven
+    on purpose: ``forward`` must notice, fall back to one launch per step and return correct logits; the
+    pipeline must raise instead of decoding NaNs into "no events"."""
+    from sound_event_detection_amd import _lib
+    from sound_event_detection_amd.pipeline import SedPipeline
+    m, sd = _shake("rcnn")
+    x = torch.from_numpy(synth.synth_shake_feats(77, 3, 400)).cuda()
+    al = [0.3, 0.5, 0.7]
+    want = m(x, al).clone()                                   # the single-launch recurrence, undisturbed
+    assert m.recurrence == "auto" and torch.isfinite(want).all()
+    monkeypatch.setenv("SEDMI_SHAKE_GRU_EXCHANGE", exchange)
+    monkeypatch.setenv("SEDMI_SHAKE_GRU_SPIN_LIMIT", "0")
+    pipe = SedPipeline(m, sr=16000, n_fft=2048, hop_length=160, win_length=640)
+    out = pipe.run_features(x, alphas=al)
+    with pytest.raises(_lib.SedmiRecurrenceError, match="gave up"):
+        pipe.events(out, {i: f"c{i}" for i in range(10)}, ["a", "b", "c"])
+    assert m.recurrence == "per_step"                         # the next run cannot fail that way
+    out = pipe.run_features(x, alphas=al)
+    ev = pipe.events(out, {i: f"c{i}" for i in range(10)}, ["a", "b", "c"])
+    assert torch.isfinite(out["probs"]).all() and (out["probs"] - want).abs().max() < 1e-4
+    # the nn.Module path: warns, switches, reruns, returns finite logits
+    m.recurrence = "auto"
+    with pytest.warns(RuntimeWarning, match="one launch per step"):
+        got = m(x, al)
+    assert m.recurrence == "per_step" and (got - want).abs().max() < 1e-4
+    monkeypatch.delenv("SEDMI_SHAKE_GRU_SPIN_LIMIT")
+    m.recurrence = "auto"
+    pipe2 = SedPipeline(m, sr=16000, n_fft=2048, hop_length=160, win_length=640)
+    out2 = pipe2.run_features(x, alphas=al)
+    assert pipe2.events(out2, {i: f"c{i}" for i in range(10)}, ["a", "b", "c"]) == ev and m.recurrence == "auto"

@@ -68,6 +68,54 @@ def test_buffers_are_reused_for_smaller_batches_and_other_recording_tables():
         pipe.run(yd, clips_per_recording=[2, 3])
 
 
+def _oracle_log_normalised(y, mean=None, std=None):
+    """oracle mel -> power_to_db -> per-bin (x - mean) / std with float64 statistics over all clips of ``y``
+    (oracle/mel.py: this build's own definitions; the reference has neither stage, training.py:91-94)."""
+    db = np.stack([omel.power_to_db(omel.melspectrogram(c, SR, N_FFT, 128, HOP, WIN)) for c in y])
+    if mean is None:
+        rows = db.astype(np.float64).transpose(1, 0, 2).reshape(128, -1)
+        mean, std = rows.mean(1), rows.std(1)
+    nz = np.stack([omel.normalise(d, mean.astype(np.float32), std.astype(np.float32)) for d in db])
+    return nz, mean, std
+
+
+def test_log_and_batch_normalisation_on_the_pipeline_match_the_oracle():
+    """SedPipeline(log=True, normalise=True): mel pass -> float64 statistics -> in-place normalisation -> CRNN
+    -> decode.  Statistics vs numpy float64, normalised features vs the oracle, probabilities vs the oracle CRNN
+    on the oracle's features (1e-3 absolute); handing the same statistics in beforehand (one pass, the stage
+    inside the mel kernel) gives the same bits; defaults stay off."""
+    from sound_event_detection_amd.pipeline import SedPipeline
+    m = _crnn(0)
+    y = synth.synth_clips(11, 5)
+    yd = torch.from_numpy(y).cuda()
+    want_feat, want_mean, want_std = _oracle_log_normalised(y)
+    pipe = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN, log=True, normalise=True)
+    out = pipe.run(yd)
+    mel = out["mel"].clone()
+    probs = out["probs"].clone()
+    mean, std = out["mel_mean"].cpu().numpy(), out["mel_std"].cpu().numpy()
+    assert mean.dtype == np.float64 and np.abs(mean - want_mean).max() < 2e-4          # dB: 1e-4 relative on S = 4e-4 dB
+    assert np.abs(std / want_std - 1).max() < 1e-4
+    assert np.abs(mel.cpu().numpy() - want_feat).max() < 2e-3
+    sd = synth.synth_crnn_state_dict(0)
+    want_probs = ocrnn.crnn_forward(sd, torch.from_numpy(want_feat.reshape(5, 501, 128))).numpy()
+    assert np.abs(probs.cpu().numpy() - want_probs).max() < 1e-3
+    # the statistics handed in: one pass, same bits
+    fixed = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN, log=True, normalise=True,
+                        mean=out["mel_mean"].clone(), std=out["mel_std"].clone())
+    out2 = fixed.run(yd)
+    assert torch.equal(out2["mel"], mel) and torch.equal(out2["probs"], probs) and "mel_mean" not in out2
+    # running it twice gives the same statistics bit for bit (fixed summation order, no atomics)
+    again = pipe.run(yd)
+    assert torch.equal(again["mel_mean"].cpu(), torch.from_numpy(mean)) and torch.equal(again["mel"], mel)
+    # defaults: neither stage
+    plain = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN).run(yd)
+    raw = np.stack([omel.melspectrogram(c, SR, N_FFT, 128, HOP, WIN) for c in y])
+    assert np.abs(plain["mel"].cpu().numpy() - raw).max() / raw.max() < 1e-5
+    with pytest.raises(ValueError):
+        SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN, mean=torch.zeros(128), std=torch.ones(128))
+
+
 def test_exchange_steps_over_rccl_on_device_tensors(tmp_path):
     """backend "nccl" is RCCL on ROCm.  One rank on the one GPU of the test box: initialises the communicator and
     runs both collectives of parallel.py on device tensors."""
@@ -109,5 +157,21 @@ def test_exchange_steps_over_rccl_on_device_tensors(tmp_path):
         m = _crnn(0)
         args = (m, names, str(tmp_path) + "/", "desed_2022", 10000, N_FFT, 128, HOP, WIN, id2cls, 40)
         assert parallel.predict_files_sharded(*args) == predict_files(*args)
+        # the normalisation stage with its all-reduce over RCCL: the pipeline with group=True (statistics summed over
+        # the group's ranks, here one) equals the pipeline without a group, and the file-level loops agree
+        from sound_event_detection_amd.pipeline import SedPipeline
+        yd = torch.from_numpy(synth.synth_clips(30, 3)).to(dev)
+        kw = dict(sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN, log=True, normalise=True)
+        a = SedPipeline(m, group=True, **kw).run(yd)
+        a_mel, a_mean = a["mel"].clone(), a["mel_mean"].clone()
+        b = SedPipeline(m, **kw).run(yd)
+        assert torch.equal(a_mel, b["mel"]) and torch.equal(a_mean, b["mel_mean"])
+        ev_n = predict_files(*args, log=True, normalise=True)
+        assert parallel.predict_files_sharded(*args, log=True, normalise=True) == ev_n
+        from sound_event_detection_amd.predict import dataset_mel_statistics
+        mean, std = dataset_mel_statistics(names, str(tmp_path) + "/", "desed_2022", 10000, N_FFT, 128, HOP, WIN,
+                                           log=True)
+        assert predict_files(*args, log=True, normalise=True, mean=mean, std=std) == ev_n
+        assert ev_n != predict_files(*args) and len(ev_n) > 0
     finally:
         dist.destroy_process_group()

@@ -46,6 +46,16 @@ def _worker(rank, world, port, n_total):
         mean, std = parallel.all_reduce_mel_stats(loc.sum((0, 2)), (loc * loc).sum((0, 2)), float(loc.shape[0] * 50))
         assert torch.allclose(mean, mel.mean((0, 2)), rtol=1e-12)
         assert torch.allclose(std, mel.std((0, 2), unbiased=False), rtol=1e-9)
+        # sharded statistics = the single-rank statistics of the same per-shard sums, bit for bit in float64
+        parts = [mel[slice(*parallel.shard_range(n_total, r, world))] for r in range(world)]
+        s_all = sum(p.sum((0, 2)) for p in parts)
+        s2_all = sum((p * p).sum((0, 2)) for p in parts)
+        mean1, std1 = parallel.mel_stats_to_mean_std(s_all, s2_all, torch.tensor(float(n_total * 50), dtype=torch.float64))
+        assert mean.dtype == torch.float64 and torch.equal(mean, mean1) and torch.equal(std, std1)
+        # a bin that never varies is not divided by zero
+        z = torch.zeros(4, dtype=torch.float64)
+        _, std0 = parallel.all_reduce_mel_stats(z, z, 10.0)
+        assert torch.all(std0 == parallel.MEL_STD_FLOOR)
     finally:
         dist.destroy_process_group()
 

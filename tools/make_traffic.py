@@ -6,7 +6,7 @@ runs of `bench.py --clips 1024 --steps 1 --warmup 1 --cpu-clips 0`).
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
 stream: a torch elementwise add in the same pass (reads 2 x 160000 KiB, reports ~160014) calibrates the
-factor 2 that is applied here.  Keys are the kernel names bench.py prints.
+factor 2 that is applied here.  Keys are the kernel names bench.py prints (= the kernels' own names with their distinguishing template arguments).
 """
 import csv
 import json
@@ -19,15 +19,17 @@ def bench_name(k):
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"conv_split_kernel<(\d+), (\d+), (\d+),", k)
     if m:
-        return "conv_split<%s,%s,%s>" % m.groups()
-    m = re.match(r"linear_split_kernel<768, (\d+),", k)
+        return "conv_split_kernel<%s,%s,%s>" % m.groups()
+    m = re.match(r"linear_split_kernel<768, (\d+), (\d+)>", k)
     if m:
-        return "gru_input_proj_split<%s>" % m.group(1)
-    for a, b in (("mel_kernel", "mel_kernel"), ("conv0_kernel", "conv0_kernel"), ("conv0_split_kernel", "conv0_kernel"),
-                 ("clip_scale_kernel", "clip_scale_kernel"), ("gru0_fused_kernel", "gru0_fused"), ("gru_split_kernel", "gru_kernel"),
-                 ("gru_kernel", "gru_kernel"), ("head_small_kernel", "head_kernel"), ("head_kernel", "head_kernel")):
+        return "linear_split_kernel<768,%s,%s>" % m.groups()
+    m = re.match(r"gru_split_kernel<(true|false)>", k)
+    if m:
+        return "gru_split_kernel<%s>" % m.group(1)
+    for a in ("mel_kernel", "conv0_split_kernel", "conv0_kernel", "gru0_fused_kernel", "gru_kernel", "head_small_kernel",
+              "head_kernel", "head_combine_kernel"):
         if k.startswith(a):
-            return b
+            return a
     return None
 
 

@@ -30,8 +30,8 @@ def main():
     torch.cuda.synchronize()
     prof = {k["name"]: k["ms"] / max(k["launches"], 1) for k in _lib.profile_collect()}
     h.sedmi_debug_split_ticks(buf)
-    names = ["conv_split<16,32,64>", "conv_split<32,64,32>", "conv_split<64,128,16>", "conv_split<128,128,8>",
-             "conv_split<128,128,4>", "conv_split<128,128,2>"]
+    names = ["conv_split_kernel<16,32,64>", "conv_split_kernel<32,64,32>", "conv_split_kernel<64,128,16>", "conv_split_kernel<128,128,8>",
+             "conv_split_kernel<128,128,4>", "conv_split_kernel<128,128,2>"]
     for layer in range(6):
         row = [buf[layer * 12 + i] for i in range(12)]
         ms = prof.get(names[layer], 0.0)
