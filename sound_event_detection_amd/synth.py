@@ -47,6 +47,35 @@ def synth_clips(first: int, count: int, n_samples: int = 160000, sr: int = 16000
     return out
 
 
+def synth_labelled_clip(index: int, n_cls: int = 10, n_samples: int = 160000, sr: int = 16000, frames: int = 250):
+    """A clip with ground truth: noise 0.05 rms plus 1..4 events, each of a class drawn at random.  Class c
+    sounds as a tone (with a weaker octave) in its own frequency band, 300 Hz * 1.35**c, amplitude-modulated at
+    3 + c Hz; an event of class c switches label[frame, c] on for the 40 ms frames it overlaps (the
+    rasterisation of utils.py:255-281).  Returns (float32 [n_samples], float32 [frames, n_cls])."""
+    rng = np.random.Generator(np.random.PCG64(80_000 + int(index)))
+    y = rng.standard_normal(n_samples).astype(np.float32) * np.float32(0.05)
+    labels = np.zeros((frames, n_cls), dtype=np.float32)
+    t = np.arange(n_samples, dtype=np.float64) / float(sr)
+    per_frame = n_samples / frames
+    for _ in range(int(rng.integers(1, 5))):
+        c = int(rng.integers(0, n_cls))
+        f0 = 300.0 * 1.35 ** c * float(rng.uniform(0.97, 1.03))
+        amp = float(rng.uniform(0.15, 0.5))
+        start = int(rng.integers(0, n_samples - sr // 2))
+        stop = min(n_samples, start + int(rng.integers(sr // 2, 4 * sr)))
+        seg = t[start:stop]
+        env = 0.6 + 0.4 * np.sin(2.0 * np.pi * (3.0 + c) * seg)
+        y[start:stop] += (amp * env * (np.sin(2.0 * np.pi * f0 * seg) + 0.3 * np.sin(4.0 * np.pi * f0 * seg))).astype(np.float32)
+        labels[int(start // per_frame):int(np.ceil(stop / per_frame)), c] = 1.0
+    return y, labels
+
+
+def synth_labelled_clips(first: int, count: int, n_cls: int = 10):
+    """(float32 [count, 160000], float32 [count, 250, n_cls]) for clip indices first .. first + count - 1."""
+    pairs = [synth_labelled_clip(first + k, n_cls) for k in range(count)]
+    return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+
 def crnn_state_dict_spec(nclass: int = 10, n_in_channel: int = 1,
                          filters=CRNN_FILTERS, hidden: int = CRNN_HIDDEN,
                          gru_layers: int = CRNN_GRU_LAYERS):

@@ -100,10 +100,19 @@ def test_mixed_levels_in_one_batch_and_degenerate_clips(precision):
     got = m(xd)
     for i in (0, 1, 3, 4, 5):
         assert torch.equal(m(xd[i:i + 1].contiguous()), got[i:i + 1])
-    want = ocrnn.crnn_forward(sd, torch.from_numpy(x)).numpy()
-    # clips 2 and 4 are ill-conditioned for any float32 arithmetic: 3e4 x louder than the checkpoint expects (see
-    # test_loud_audio_with_unmatched_checkpoint_stays_finite), and a spike that puts values of ~1e4 next to O(1)
-    # ones inside the later blocks' dot products (the exact-float32 mode differs from the CPU by 5e-3 there too)
-    ok = [0, 1, 3, 5]
-    assert np.abs(got.cpu().numpy()[ok] - want[ok]).max() < PROB_TOL
+    # Reference arithmetic in float64 as the yardstick, and the error the reference's own float32 evaluation (CPU,
+    # torch) makes against it, per clip.  Clips 0, 1, 3, 5 are well conditioned (float32 vs float64: ~3e-7) and
+    # must meet the 1e-3 tolerance.  Clip 2 (3e4 x louder than the checkpoint expects: every gate a step function)
+    # and clip 4 (one 6e4 spike in an O(1) clip: values of ~1e4 next to O(1) ones inside the later blocks' dot
+    # products) are ill-conditioned for ANY float32 arithmetic -- the float32 CPU evaluation is 0.43 and 2.1e-3
+    # away from float64 on them (pinned in tests/test_oracle_crnn.py) -- so there the HIP path is held to the
+    # same yardstick with the float32 CPU path's own error as the allowance.
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    want64 = ocrnn.crnn_forward(sd64, torch.from_numpy(x).double(), explicit_gru=True).numpy()
+    cpu32 = ocrnn.crnn_forward(sd, torch.from_numpy(x)).numpy()
+    g = got.cpu().numpy()
+    for i in range(6):
+        cpu_err = float(np.abs(cpu32[i] - want64[i]).max())
+        gpu_err = float(np.abs(g[i] - want64[i]).max())
+        assert gpu_err <= max(PROB_TOL, 3.0 * cpu_err), (i, gpu_err, cpu_err)
     assert torch.isfinite(got).all()

@@ -1,0 +1,83 @@
+"""Parity on a checkpoint that has been TRAINED (needs an MI355X).
+
+tests/golden/crnn_trained.npz holds the state_dict the reference's own CRNN had after a few hundred steps of the
+reference's training step (Adam, BCE, dropout 0.5, BatchNorm momentum 0.99: training.py:213,258-273,
+nnet/CNN.py:76) on labelled synthetic clips, and the probabilities the reference's CRNN.forward gave in eval
+mode for eight held-out clips (oracle/make_golden.py::make_crnn_trained).  Unlike the deterministic synthetic
+weights of synth.py, nothing in this checkpoint was conditioned by hand: BatchNorm running statistics and every
+weight come out of real forward / backward passes.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import acceptance as oacc, mel as omel
+from sound_event_detection_amd import synth
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-3
+SR, N_FFT, HOP, WIN = 16000, 2048, 320, 640
+
+
+def _load(golden_dir):
+    g = np.load(os.path.join(golden_dir, "crnn_trained.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    first, n = (int(v) for v in g["first_eval"])
+    y, labels = synth.synth_labelled_clips(first, n, 10)
+    return sd, y, labels, g["probs"]
+
+
+def _model(sd, precision):
+    from sound_event_detection_amd.nnet import CRNN
+    m = CRNN(dropout=0.5, rnn_layers=2, n_in_channel=1, nclass=10, attention=True, n_RNN_cell=128, activation='glu',
+             rnn_type='BGRU', kernel_size=[3] * 7, padding=[1] * 7, stride=[1] * 7,
+             nb_filters=[16, 32, 64, 128, 128, 128, 128], pooling=[[2, 2]] + [[1, 2]] * 6, dropout_recurrent=0)
+    m.load_state_dict(sd)
+    m.eval()
+    m.conv_precision = precision
+    return m.cuda()
+
+
+@pytest.mark.parametrize("precision", ["split_f16", "f32"])
+def test_trained_checkpoint_matches_the_reference_forward(golden_dir, precision):
+    """Features from the oracle's mel (what the reference's probabilities were computed from) through the HIP
+    CRNN: <= 1e-3 absolute on the probabilities, in both arithmetic modes."""
+    sd, y, labels, want = _load(golden_dir)
+    assert len(sd) == 83 and want.shape == (len(y), 250, 10)
+    feats = np.stack([omel.clip_feature(c, SR, N_FFT, 128, HOP, WIN) for c in y]).astype(np.float32)
+    got = _model(sd, precision)(torch.from_numpy(feats).cuda()).cpu().numpy()
+    err = float(np.abs(got - want).max())
+    print(f"trained checkpoint, {precision}: max |dp| vs the reference's CRNN.forward = {err:.2e}")
+    assert err < PROB_TOL
+    # the checkpoint did learn something: it is not a constant predictor
+    assert ((want > 0.5) == (labels > 0.5)).mean() > 0.9 and (want > 0.5).mean() > 0.02
+
+
+@pytest.mark.parametrize("precision", ["split_f16", "f32"])
+def test_trained_checkpoint_events_from_audio_meet_the_acceptance_rule(golden_dir, precision):
+    """Audio -> HIP mel -> HIP CRNN -> HIP decode against the reference's probabilities through the reference's
+    decoder: every frame whose thresholded bit differs lies within 1e-3 of the threshold on the reference side,
+    and with those frames masked the event lists are identical (float64 times bit for bit)."""
+    from sound_event_detection_amd.pipeline import SedPipeline
+    sd, y, _, want = _load(golden_dir)
+    m = _model(sd, precision)
+    pipe = SedPipeline(m, sr=SR, n_fft=N_FFT, hop_length=HOP, win_length=WIN)
+    out = pipe.run(torch.from_numpy(y).cuda())
+    got = out["probs"].cpu().numpy()
+    assert float(np.abs(got - want).max()) < PROB_TOL
+    p_cpu, p_gpu = want.reshape(-1, 10), got.reshape(-1, 10)
+    n_diff, n_bad, near = oacc.frame_differences(p_cpu, p_gpu, 0.5, PROB_TOL, False)
+    assert n_bad == 0, f"{n_bad} of {n_diff} differing frames lie further than {PROB_TOL} from the threshold"
+    id2cls = {i: f"cls{i}" for i in range(10)}
+    names = [f"clip{i}" for i in range(len(y))]
+    counts, durations = [1] * len(y), [10.0] * len(y)
+    # the pipeline's events are the reference decoder's events of the pipeline's own frame predictions ...
+    assert pipe.events(out, id2cls, names) == oacc.cpu_events(p_gpu, counts, 250, names, id2cls, durations, 40)
+    # ... and with the frames within tolerance of the threshold masked on both sides the lists are identical
+    ev_ref = oacc.cpu_events(oacc.masked(p_cpu, near, 0.5, False), counts, 250, names, id2cls, durations, 40)
+    ev_gpu = oacc.cpu_events(oacc.masked(p_gpu, near, 0.5, False), counts, 250, names, id2cls, durations, 40)
+    assert ev_gpu == ev_ref and len(ev_ref) > 0
+    print(f"trained checkpoint from audio, {precision}: {n_diff} differing frames (all within tolerance), "
+          f"{int(near.sum())} frames within {PROB_TOL} of the threshold, {len(ev_ref)} events")
