@@ -518,15 +518,24 @@ __global__ __launch_bounds__(1024) void mel_stats_kernel(const float *mel, long 
                                                          double *sum, double *sumsq) {
     const int m = blockIdx.x;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    double s = 0.0, s2 = 0.0;
+    // four independent partial sums per thread (frames tx + 64 (4 i + u)), so that four loads are in flight
+    // per thread; the partials are added in a fixed order
+    double ps[4] = {0.0, 0.0, 0.0, 0.0}, ps2[4] = {0.0, 0.0, 0.0, 0.0};
     for (long c = ty; c < n_clips; c += 16) {
         const float *row = mel + (c * n_mels + m) * T;
-        for (long t = tx; t < T; t += 64) {
-            const double v = row[t];
-            s += v;
-            s2 += v * v;
+        for (long t0 = tx; t0 < T; t0 += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t0 + 64 * u < T ? row[t0 + 64 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d = v[u];
+                ps[u] += d;
+                ps2[u] += d * d;
+            }
         }
     }
+    const double s = (ps[0] + ps[1]) + (ps[2] + ps[3]), s2 = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
     __shared__ double sh[2][1024];
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = s2;
