@@ -144,11 +144,12 @@ constexpr int C2_TR = 8, C2_TC = 32;
 // columns a tile advances by: a (1,5) pooling window needs 4 more conv columns than it yields outputs
 __host__ __device__ constexpr int c2_xstride(int mode) { return mode == MODE_POOL_W5 ? C2_TC - 4 : C2_TC; }
 
-template <int CIN, int N, int CCH>
+// TR: rows of a workgroup's tile (8, or 16 where 16-channel chunks leave room for two such workgroups per CU)
+template <int CIN, int N, int CCH, int TR = C2_TR>
 struct Conv2dGeom {
     static constexpr int TW = C2_TC + 2;
     static constexpr int PSB = CCH * 2 + 16;
-    static constexpr int PLANE = (C2_TR + 2) * TW * PSB;
+    static constexpr int PLANE = (TR + 2) * TW * PSB;
     static constexpr int LDS_BYTES = 2 * PLANE;
     static constexpr int NCHUNK = CIN / CCH;
     static constexpr int KS = CCH / 16;
@@ -172,7 +173,7 @@ __device__ __forceinline__ void tile_pos(int p, int &ty, int &tx) {
 
 // WN: waves across the N columns (1: every wave has all of them and 64 positions; 2: a wave has every second
 // 32-column tile and 128 positions, so that the weights it reads from L2 feed twice the MFMAs).
-template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN>
+template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN, int TR = C2_TR>
 __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     const float *__restrict__ x,      // [clip][H][W][CIN]
     const uint4 *__restrict__ wp,     // packed split weights [9*CIN/16][2][N][16], k-step order chunk/tap/k
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                                       // MODE_POOL_NCHW: [clip][N][H/2][W/2] (the same, max-pooled, ReLU);
                                       // MODE_POOL_W5: [clip][H][W-4][N] (the same, (1,5) max-pooled, ReLU)
     int H, int W, int tiles_x, int tiles_y, unsigned n_tiles) {
-    using G = Conv2dGeom<CIN, N, CCH>;
-    constexpr int NT = G::NT / WN, MT = 2 * WN, CO = N / 2, PWV = 64 * WN;      // NT: column tiles per wave
+    using G = Conv2dGeom<CIN, N, CCH, TR>;
+    constexpr int NT = G::NT / WN, MT = TR * WN / 4, CO = N / 2, PWV = 32 * MT;   // NT: column tiles per wave
+    static_assert(TR % 8 == 0 && (MODE != MODE_POOL_W5 || TR == 8), "tile rows");
     static_assert(G::NT % (2 * WN) == 0 || WN == 1, "a wave needs both halves of the GEMM columns");
     static_assert(MODE != MODE_GATE || CIN == CO, "the gate multiplies the conv input channel by channel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     if (static_cast<unsigned>(bid) >= n_tiles) return;
     const int tx0 = (bid % tiles_x) * c2_xstride(MODE);
     bid /= tiles_x;
-    const int ty0 = (bid % tiles_y) * C2_TR;
+    const int ty0 = (bid % tiles_y) * TR;
     const long clip = bid / tiles_y;
     const float *xc = x + clip * static_cast<long>(H) * W * CIN;
 
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     }
     const uint4 *bp = wp + (col32 + 32 * wn) * 2 + half;
 
-    constexpr int POS = (C2_TR + 2) * G::TW;
+    constexpr int POS = (TR + 2) * G::TW;
     constexpr int STAGE_F4 = POS * (CCH / 4);
     constexpr int NLD = (STAGE_F4 + 255) / 256;
     using f32x4v = __attribute__((ext_vector_type(4))) float;
@@ -1737,14 +1739,17 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind, int num_cus = 0) {
 // kernels with 128 GEMM columns split them over two waves (gate<64> 3.04 -> 2.74 ms, conv<32,128> 1.56 -> 1.51 ms per
 // 128 clips); requesting the next input chunk before the MFMAs of the current one on top of that gained nothing
 constexpr int C2_WN = 2;
-template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN = 1>
+#ifndef SHAKE_TR16
+#define SHAKE_TR16 8          // tile rows of the two kernels that stage 16-channel chunks
+#endif
+template <int CIN, int N, int CCH, int MODE, int PH, int PW, int WN = 1, int TR = C2_TR>
 int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const float *et, float alpha, const float *s2,
                   const float *t2, const float *x, float *y, long n, int H, int W, hipStream_t s) {
-    using G = Conv2dGeom<CIN, N, CCH>;
+    using G = Conv2dGeom<CIN, N, CCH, TR>;
     const int tiles_x = static_cast<int>(MODE == MODE_POOL_W5 ? sedmi::ceil_div(W - 4, C2_TC - 4) : sedmi::ceil_div(W, C2_TC));
-    const int tiles_y = static_cast<int>(sedmi::ceil_div(H, C2_TR));
+    const int tiles_y = static_cast<int>(sedmi::ceil_div(H, TR));
     if (4.0 * H * W * CIN >= 2147483648.0) return SEDMI_EINVAL;      // one clip's input is addressed with 32-bit offsets
-    auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN>;
+    auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN, TR>;
     if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), G::LDS_BYTES)) return rc_lds;
     const double pos = static_cast<double>(n) * H * W;
     sedmi::ProfileScope prof(name, s, pos * 2.0 * 9 * CIN * N,
@@ -1774,9 +1779,9 @@ int run_shake_cnn(const ShakeCnnDev *m, const float *feats, long n, int T, const
         }
         int rc;
         const BlockDev *b = m->blk;
-        if ((rc = launch_conv2d<16, 32, 16, MODE_GATE, 2, 2>("shake_gate<16>", b[0].wb, b[0].es_b, b[0].et_b, alphas[0],
+        if ((rc = launch_conv2d<16, 32, 16, MODE_GATE, 2, 2, 1, SHAKE_TR16>("shake_gate<16>", b[0].wb, b[0].es_b, b[0].et_b, alphas[0],
                                                             b[0].s2, b[0].t2, sc.u1, sc.y1, nc, T, 768, s))) return rc;
-        if ((rc = launch_conv2d<16, 64, 16, MODE_GLU, 1, 1>("shake_conv<16,64>", b[1].wa, b[1].es_a, b[1].et_a, 0.f,
+        if ((rc = launch_conv2d<16, 64, 16, MODE_GLU, 1, 1, 1, SHAKE_TR16>("shake_conv<16,64>", b[1].wa, b[1].es_a, b[1].et_a, 0.f,
                                                            nullptr, nullptr, sc.y1, sc.u2, nc, T2, 384, s))) return rc;
         if ((rc = launch_conv2d<32, 64, 32, MODE_GATE, 2, 2>("shake_gate<32>", b[1].wb, b[1].es_b, b[1].et_b, alphas[1],
                                                             b[1].s2, b[1].t2, sc.u2, sc.y2, nc, T2, 384, s))) return rc;

@@ -140,3 +140,48 @@ def test_other_models_events_from_audio_match_the_cpu_path(kind):
     assert np.abs(p_gpu - p_cpu).max() < 4e-3          # logits; probabilities move by at most a quarter of this
     n_diff, n_near, n_events = _check(p_cpu, p_gpu, gpu_events, counts, frames, names, durations, id2cls, True)
     print(f"{kind}: {n_diff} differing frames, {n_near} frames within {TOL} of the threshold, {n_events} events")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dataset,sr,win,hop,n_cls", [("BirdSED", 16000, 640, 320, 92), ("BirdSED-1", 16000, 640, 320, 1),
+                                                       ("TUT", 44100, 1764, 882, 6)])
+def test_crnn_events_for_each_dataset_shape_match_the_cpu_path(dataset, sr, win, hop, n_cls):
+    """The three dataset configurations of the reference from audio to events: BirdSED with its 92 classes
+    (utils.py:13; the head runs as a kernel of its own beyond 16 classes) and as a single class (utils.py:54-55;
+    the reference's squeeze() then hands the decoder a 1-D array, evaluation.py:62-63), and TUT at 44.1 kHz with 6
+    classes (feature_extraction.py:10, utils.py:12: win 1764, hop 882 from training.py:160-162 -> 501 frames)."""
+    from sound_event_detection_amd.nnet import CRNN
+    from sound_event_detection_amd.pipeline import SedPipeline
+    n = 6
+    n_samples = 10 * sr
+    # the synthetic checkpoint's BatchNorm statistics belong to power mels of a 640-sample window: a longer window
+    # collects proportionally more of a tone's energy, so the recording is made that much quieter
+    y = np.stack([synth.synth_clip(500 + i, n_samples, sr) for i in range(n)]) * np.float32(640.0 / win)
+    sd = synth.synth_crnn_state_dict(7, nclass=n_cls)
+    feats = np.stack([omel.clip_feature(c, sr, N_FFT, 128, hop, win) for c in y])
+    assert feats.shape == (n, 501, 128)
+    p_cpu = ocrnn.crnn_forward(sd, torch.from_numpy(feats)).numpy()
+    m = CRNN(dropout=0.5, rnn_layers=2, n_in_channel=1, nclass=n_cls, attention=True, n_RNN_cell=128, activation='glu',
+             rnn_type='BGRU', kernel_size=[3] * 7, padding=[1] * 7, stride=[1] * 7,
+             nb_filters=[16, 32, 64, 128, 128, 128, 128], pooling=[[2, 2]] + [[1, 2]] * 6, dropout_recurrent=0)
+    m.load_state_dict(sd)
+    m.eval()
+    m = m.cuda()
+    counts, names, durations = [2, 1, 3], ["a.wav", "b.wav", "c.wav"], [17.5, 10.0, 30.0]
+    cutoffs = [odec.cutoff_frames(d, 40) for d in durations]
+    id2cls = {i: f"cls{i}" for i in range(n_cls)}
+    pipe = SedPipeline(m, sr=sr, n_fft=N_FFT, hop_length=hop, win_length=win)
+    out = pipe.run(torch.from_numpy(y).cuda(), clips_per_recording=counts, cutoffs=cutoffs)
+    gpu_events = pipe.events(out, id2cls, names)
+    p_gpu = out["probs"].cpu().numpy()
+    assert p_gpu.shape == p_cpu.shape == (n, 250, n_cls)
+    assert np.abs(p_gpu - p_cpu).max() < 1e-3
+    n_diff, n_near, n_events = _check(p_cpu, p_gpu, gpu_events, counts, 250, names, durations, id2cls, False)
+    print(f"{dataset}: {n_diff} differing frames, {n_near} frames within {TOL} of the threshold, {n_events} events")
+    if n_cls == 1:
+        # what the reference's prediction loop hands over after squeeze() (training.py:348): a 1-D array per file
+        from sound_event_detection_amd import evaluation as ev
+        flat = torch.from_numpy(acceptance.masked(p_cpu.reshape(-1, 1), np.abs(p_cpu.reshape(-1, 1) - THR) <= TOL, THR, False))
+        one_d = ev.get_prediction_from_raw_output(flat[:500, 0].cuda(), id2cls, 17.5, 40, "a.wav", THR, False)
+        two_d = odec.get_prediction_from_raw_output(flat[:500].numpy(), id2cls, 17.5, 40, "a.wav", THR, False)
+        _same_events(one_d, two_d)
