@@ -139,3 +139,33 @@ def test_confusion_counts_and_evaluate_scores():
     assert np.isclose(res["precision"], precision_score(y.flatten(), yh.flatten(), zero_division=0.0))
     assert np.isclose(res["recall"], recall_score(y.flatten(), yh.flatten(), zero_division=0.0))
     assert np.isclose(res["accuracy"], accuracy_score(y.flatten(), yh.flatten()))
+
+
+def test_decode_fuzz_many_shapes_vs_oracle():
+    """Seeded random recording tables: 1 to 92 classes, recordings of 0 to 1500 frames (empty ones, one-frame ones,
+    lengths either side of the 64 frames a wave walks per step), cutoffs of 0, inside, at and beyond the recording,
+    thresholds other than 0.5, sticky and flickering maps.  Bit-exact against the reference's decode rule
+    (evaluation.py:58-78) restated in the oracle, recording by recording."""
+    from sound_event_detection_amd import evaluation as ev
+    rng = np.random.Generator(np.random.PCG64(2025))
+    for case in range(40):
+        n_cls = int(rng.choice([1, 2, 3, 6, 7, 10, 16, 17, 33, 64, 92]))
+        n_rec = int(rng.integers(1, 9))
+        lens = [int(rng.choice([0, 1, 2, 63, 64, 65, 127, 128, 129, 250, int(rng.integers(3, 1500))])) for _ in range(n_rec)]
+        cut = [int(rng.choice([0, 1, max(n // 2, 0), n, n + 1, n + 1000])) for n in lens]
+        thr = float(rng.choice([0.5, 0.3, 0.71]))
+        total = sum(lens)
+        if rng.random() < 0.5:                                      # sticky runs
+            z = rng.normal(0, 1, (total + 8, n_cls))
+            z = np.stack([np.convolve(z[:, c], np.ones(9) / 9, mode="same") for c in range(n_cls)], 1)[:total]
+            p = (1 / (1 + np.exp(-4 * z))).astype(np.float32)
+        else:                                                       # flicker, with exact ties at the threshold
+            p = rng.uniform(0, 1, (total, n_cls)).astype(np.float32)
+            p[rng.random((total, n_cls)) < 0.05] = np.float32(thr)  # strict '>': a tie is off
+        seg, cls, on, off = ev.decode_recordings(torch.from_numpy(p).cuda(), lens, cut, thr)
+        want, o = [], 0
+        for s, (n, c) in enumerate(zip(lens, cut)):
+            want += [(s, cc, a, b) for (cc, a, b) in odec.decode_events(odec.threshold(p[o:o + n], thr), c)]
+            o += n
+        got = list(zip(seg.tolist(), cls.tolist(), on.tolist(), off.tolist()))
+        assert got == want, (case, n_cls, lens, cut, thr)
