@@ -31,7 +31,8 @@ Rank 0 prints ONE JSON line carrying, besides the contract fields,
   roofline      the dominant kernel's achieved algorithmic rate vs its MI355X peak, timed with HIP events
                 on the launch stream inside this run (all kernels are listed under "kernels");
   cpu_baseline  the CPU oracle (same arithmetic and primitives as the reference's CPU path) timed on this
-                host on a bounded sample of the same input, in the ways the reference runs it.
+                host on a bounded sample of the same input, in the ways the reference runs it (N = 1 only; with
+                more ranks pass --cpu-clips to ask for it).
 """
 from __future__ import annotations
 
@@ -486,6 +487,10 @@ def main():
         cpu = acceptance = None
         extra = {}
         n_cpu = args.cpu_clips
+        if world > 1 and n_cpu is None:
+            # the CPU leg is timed at N = 1 only: under a launcher every rank usually gets a single OpenMP thread,
+            # which would turn a 25 s check into minutes while the other ranks wait at the final barrier
+            n_cpu = 0
         if kind == "crnn":
             n_cpu = 192 if n_cpu is None else n_cpu
             if n_cpu > 0:
@@ -503,7 +508,7 @@ def main():
                 acceptance = dict(sample_clips=ns, frames_differing=n_diff, frames_differing_out_of_tolerance=n_bad,
                                   frames_within_tolerance_of_threshold=int(near.sum()), tolerance=1e-3, events_cpu=len(cpu_events),
                                   events_gpu=len(gpu_events), event_lists_identical=gpu_events == cpu_events)
-            if model.conv_precision == "split_f16" and not args.no_exact_leg:
+            if model.conv_precision == "split_f16" and not args.no_exact_leg and world == 1:
                 # the same path in exact-float32 arithmetic, outside the timed region above
                 model.conv_precision = "f32"
                 pipe.run(y)
