@@ -115,7 +115,7 @@ int sedmi_profile_collect(sedmi_kernel_stat *out, int capacity) {
     return n;
 }
 
-int sedmi_version(void) { return 100; }
+int sedmi_version(void) { return 300; }
 
 const char *sedmi_last_error(void) { return sedmi::error_buffer(); }
 
