@@ -56,6 +56,12 @@ PEAK_F32_VALU_TFLOPS = 157.3      # MI355X dense f32 vector (= f32-input MFMA) p
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X dense f16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0            # MI355X HBM3E peak
 
+# SEDMI_BENCH_REHEARSAL=cpu: the rank bookkeeping of a multi-process run (rendezvous, device check, both collectives,
+# per-rank times, the JSON line) on gloo / CPU tensors with a stand-in step that runs NO kernel.  It exists so that
+# the N > 1 code path can be executed where there is no multi-GPU machine (tests/test_bench_cpu.py); its line is marked
+# and carries no performance figure.
+REHEARSAL = os.environ.get("SEDMI_BENCH_REHEARSAL") == "cpu"
+
 CONFIGS = {
     # name: (clips per GPU, kind)
     "crnn": 4096, "frontend": 4096, "rcnn": 128, "transformer": 128, "basic": 1024, "rcnn-long": 4,
@@ -242,6 +248,9 @@ def launch_ranks(n):
 # ------------------------------------------------------------------------------------------------ rank bookkeeping
 def device_identity(rank, local_rank):
     """What tells this rank's GPU from every other rank's: host name + PCI address (+ the device UUID)."""
+    if REHEARSAL:       # no GPU: the process stands in for its device
+        return dict(rank=rank, local_rank=local_rank, host=socket.gethostname(), pci=f"pid:{os.getpid()}", uuid="",
+                    name="cpu (rehearsal)", cus=0)
     p = torch.cuda.get_device_properties(local_rank)
     pci = f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(getattr(p, 'pci_bus_id', -1)):02x}:{int(getattr(p, 'pci_device_id', -1)):02x}"
     return dict(rank=rank, local_rank=local_rank, host=socket.gethostname(), pci=pci, uuid=str(getattr(p, "uuid", "")),
@@ -265,6 +274,110 @@ def check_ranks(identities, n_gpus, world_size):
         seen[key] = i["rank"]
     return [dict(rank=i["rank"], host=i["host"], pci=i["pci"], uuid=i["uuid"], name=i["name"], cus=i["cus"])
             for i in sorted(identities, key=lambda i: i["rank"])]
+
+
+def gather_rank_times(dist, elapsed, steps, world, device):
+    """(slowest rank's elapsed seconds, every rank's ms per step): value is computed from the slowest rank."""
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    rank_ms = [1e3 * elapsed / steps]
+    if dist is not None:
+        every = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, t)
+        rank_ms = [1e3 * float(v) / steps for v in every.cpu()]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), rank_ms
+
+
+class AsyncGather:
+    """Snapshot + asynchronous all-gather of a step's frame predictions: the collective runs on the backend's own
+    stream beside the next step's kernels; slot i is reused two steps later, after waiting for the collective that
+    read it."""
+
+    def __init__(self, dist, world, device, collectives, backend):
+        self.dist, self.world, self.device, self.collectives, self.backend = dist, world, device, collectives, backend
+        self.snap, self.gathered, self.works, self.count = [None, None], [None, None], [None, None], 0
+
+    def __call__(self, p):
+        i = self.count % 2
+        self.count += 1
+        if self.snap[i] is None:
+            self.snap[i] = torch.empty_like(p)
+            # the ranks' blocks concatenated along the first axis: the form every backend takes
+            self.gathered[i] = torch.empty((self.world * p.shape[0],) + tuple(p.shape[1:]), dtype=p.dtype, device=self.device)
+            if i == 0:
+                self.collectives.append(dict(name="all_gather of the float32 frame predictions", backend=self.backend,
+                                             bytes_per_rank_per_step=p.numel() * 4, calls_per_step=1, blocking=False))
+        if self.works[i] is not None:
+            self.works[i].wait()
+        self.snap[i].copy_(p)
+        self.works[i] = self.dist.all_gather_into_tensor(self.gathered[i], self.snap[i], async_op=True)
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+
+
+def stats_collective(backend):
+    return dict(name="all_reduce(sum) of the float64 mel statistics (2 * n_mels + 1 doubles)", backend=backend,
+                bytes_per_rank_per_step=8 * (2 * 128 + 1), calls_per_step=1, blocking=True)
+
+
+def rank_fields(world, dist, ranks_seen, local_rank, rank_ms, collectives):
+    """What proves a line: the process group's size, each rank's device (all different, or no line is printed), each
+    rank's own time per step (value uses the slowest), the collectives a step ran."""
+    return {
+        "world_size": world if dist is None else dist.get_world_size(),
+        "ranks_seen": ranks_seen if ranks_seen is not None else [check_ranks([device_identity(0, local_rank)], 1, 1)[0]],
+        "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(v, 3) for v in rank_ms]},
+        "collectives": collectives,
+    }
+
+
+def rehearse(args, world, rank, dist, ranks_seen):
+    """The multi-rank bookkeeping of main() around a stand-in step (see REHEARSAL): same helpers, no kernel."""
+    from sound_event_detection_amd import parallel
+    device = torch.device("cpu")
+    steps = args.steps if args.steps is not None else 2
+    clips = args.clips if args.clips is not None else 8
+    collectives = [stats_collective("gloo")] if world > 1 and args.normalise else []
+    gather = AsyncGather(dist, world, device, collectives, "gloo") if world > 1 and not args.no_gather else None
+    g = torch.Generator().manual_seed(rank)
+
+    def step():
+        probs = torch.rand(clips, 250, N_CLS, generator=g)
+        if args.normalise and dist is not None:
+            mel = torch.rand(clips, 128, 501, generator=g, dtype=torch.float64)
+            parallel.all_reduce_mel_stats(mel.sum((0, 2)), (mel * mel).sum((0, 2)), float(clips * 501))
+        if gather is not None:
+            gather(probs)
+        return probs
+
+    def fence():
+        if gather is not None:
+            gather.wait()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed, rank_ms = gather_rank_times(dist, time.perf_counter() - t0, steps, world, device)
+    if gather is not None:      # every rank's block arrived in rank order
+        last = gather.gathered[(gather.count - 1) % 2].view(world, clips, 250, N_CLS)
+        assert torch.equal(last[rank], gather.snap[(gather.count - 1) % 2])
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (no kernel ran): rank bookkeeping on gloo / CPU", "value": None, "unit": "clips/s",
+                          "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+                          "rehearsal": True, "config": {"name": args.config, "clips_per_gpu": clips},
+                          **rank_fields(world, dist, ranks_seen, 0, rank_ms, collectives)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -300,24 +413,33 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line whose n_gpus "
                          f"differs from what was asked for")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if REHEARSAL:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    sync = (lambda: None) if REHEARSAL else (lambda: torch.cuda.synchronize(device))
     dist = None
     ranks_seen = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         identities = [None] * world
         dist.all_gather_object(identities, device_identity(rank, local_rank))
         ranks_seen = check_ranks(identities, args.gpus, dist.get_world_size())     # every rank exits on a bad layout
 
+    cfg = args.config
+    if REHEARSAL:
+        return rehearse(args, world, rank, dist, ranks_seen)
     from sound_event_detection_amd import _lib, feature_extraction as fe
     from sound_event_detection_amd.pipeline import SedPipeline
 
-    cfg = args.config
     kind = cfg.split("-")[0]
     clips = args.clips if args.clips is not None else CONFIGS[cfg]
     steps = args.steps if args.steps is not None else (3 if cfg in ("crnn", "frontend", "basic") else 2)
@@ -366,42 +488,23 @@ def main():
         dtype = "f32 (contractions as split-f16 x3 on the f16 matrix cores, f32 accumulate)"
         step_fn = lambda: pipe.run_features(x, alphas=alphas)                        # noqa: E731
 
-    gather = world > 1 and not args.no_gather and kind != "frontend"
-    collectives = []
-    if world > 1 and args.normalise:
-        collectives.append(dict(name="all_reduce(sum) of the float64 mel statistics (2 * n_mels + 1 doubles)",
-                                backend="nccl (RCCL)", bytes_per_rank_per_step=8 * (2 * 128 + 1), calls_per_step=1,
-                                blocking=True))
-    snap, gathered, works, counter = [None, None], [None, None], [None, None], [0]
+    collectives = [stats_collective("nccl (RCCL)")] if world > 1 and args.normalise else []
+    gather = (AsyncGather(dist, world, device, collectives, "nccl (RCCL)")
+              if world > 1 and not args.no_gather and kind != "frontend" else None)
 
     def step():
         b = step_fn()
-        if gather:
-            # snapshot + asynchronous all-gather: RCCL runs it on its own stream beside the next step's kernels;
-            # slot i is reused two steps later, after waiting for the collective that read it
-            i = counter[0] % 2
-            counter[0] += 1
-            p = b["probs"]
-            if snap[i] is None:
-                snap[i] = torch.empty_like(p)
-                gathered[i] = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device=device)
-                if i == 0:
-                    collectives.append(dict(name="all_gather of the float32 frame predictions", backend="nccl (RCCL)",
-                                            bytes_per_rank_per_step=p.numel() * 4, calls_per_step=1, blocking=False))
-            if works[i] is not None:
-                works[i].wait()
-            snap[i].copy_(p)
-            works[i] = dist.all_gather_into_tensor(gathered[i], snap[i], async_op=True)
+        if gather is not None:
+            gather(b["probs"])
         return b
 
     def fence():
-        for w in works:
-            if w is not None:
-                w.wait()
-        torch.cuda.synchronize(device)
+        if gather is not None:
+            gather.wait()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -415,14 +518,7 @@ def main():
     kernels = _lib.profile_collect()
     _lib.profile_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    rank_ms = [1e3 * elapsed / steps]
-    if dist is not None:
-        every = torch.zeros(world, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(every, t)
-        rank_ms = [1e3 * float(v) / steps for v in every.cpu()]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, rank_ms = gather_rank_times(dist, elapsed, steps, world, device)
     if pipe is not None and "n_events" in b:
         pipe.check(b)               # a kernel that reported a failed run makes this raise: no line from NaN logits
     n_events = int(b["n_events"].item()) if "n_events" in b else None
@@ -560,15 +656,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "name": cfg, "clips_per_gpu": clips,
                        "parallelism": f"clip-sharded x{world}",
-                       "all_gather": "float32 frame predictions, asynchronous, every step" if gather else "none",
+                       "all_gather": "float32 frame predictions, asynchronous, every step" if gather is not None else "none",
                        "events_last_step": n_events},
-            # what proves the line: the process group's size, each rank's device (all different, or no line is
-            # printed), each rank's own time per step (value uses the slowest), the collectives a step ran
-            "world_size": world if dist is None else dist.get_world_size(),
-            "ranks_seen": ranks_seen if ranks_seen is not None else [check_ranks(
-                [device_identity(0, local_rank)], 1, 1)[0]],
-            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(v, 3) for v in rank_ms]},
-            "collectives": collectives,
+            **rank_fields(world, dist, ranks_seen, local_rank, rank_ms, collectives),
             **extra,
             "roofline": roof,
             "cpu_baseline": cpu,

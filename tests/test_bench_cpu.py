@@ -54,3 +54,28 @@ def test_a_multi_gpu_line_needs_as_many_different_devices_as_ranks():
 def test_normalise_is_refused_for_configs_that_do_not_have_the_stage():
     r = _run(["--config", "rcnn", "--normalise"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--normalise applies" in r.stderr and r.stdout.strip() == ""
+
+
+def test_two_rank_rehearsal_runs_the_multi_rank_bookkeeping_on_gloo():
+    """SEDMI_BENCH_REHEARSAL=cpu: the code an N > 1 run goes through around its steps -- starting the ranks,
+    rendezvous, the all-gathered device check, the asynchronous all-gather of the predictions and the statistics
+    all-reduce every step, per-rank times, the JSON line -- executed with two processes on gloo and a stand-in step
+    that runs no kernel.  The line is marked as a rehearsal and carries no throughput."""
+    import json
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--normalise"], {"SEDMI_BENCH_REHEARSAL": "cpu"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["value"] is None and "REHEARSAL" in d["metric"]
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 3
+    assert [x["rank"] for x in d["ranks_seen"]] == [0, 1] and d["ranks_seen"][0]["pci"] != d["ranks_seen"][1]["pci"]
+    assert len(d["ms_per_step_ranks"]["all"]) == 2 and d["ms_per_step_ranks"]["max"] >= d["ms_per_step_ranks"]["min"] > 0
+    names = [c["name"] for c in d["collectives"]]
+    assert any("all_reduce" in n for n in names) and any("all_gather" in n for n in names)
+    gather = next(c for c in d["collectives"] if "all_gather" in c["name"])
+    assert gather["bytes_per_rank_per_step"] == 8 * 250 * 10 * 4 and gather["blocking"] is False
+    # a launcher's environment (the way the driver starts it) works the same
+    r1 = _run(["--gpus", "1", "--steps", "1"], {"SEDMI_BENCH_REHEARSAL": "cpu", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    d1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert r1.returncode == 0 and d1["n_gpus"] == 1 and d1["collectives"] == [] and len(d1["ranks_seen"]) == 1
