@@ -38,6 +38,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 
 namespace {
@@ -1843,12 +1845,36 @@ bool gru_exchange_by_flags(int groups_per_workgroup) {
     return groups_per_workgroup > 1;
 }
 
+// Can `blocks` workgroups of this kernel be resident at the same time on this device?  The runtime's occupancy
+// figure (registers, LDS, waves per CU) times the number of CUs; asked once per kernel and device.  It says nothing
+// about OTHER work on the GPU -- that case is caught by the bounded spins and reported by sedmi_shake_rcnn_check.
+bool persistent_grid_fits(const void *kern, int blocks, int num_cus) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> per_cu;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_cu.find({kern, device});
+    if (it == per_cu.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 512, GP_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            nb = 0;
+        }
+        it = per_cu.emplace(std::make_pair(kern, device), nb).first;
+    }
+    return static_cast<long>(it->second) * num_cus >= blocks;
+}
+
+constexpr int kPersistentDoesNotFit = 1;      // launch_gru_persistent: use one launch per step instead
+
 template <int G, int MT>
 int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_groups, int n_sets, const ShakeScratch &sc,
                           hipStream_t s) {
     if (!gru_exchange_by_flags(G)) {
         auto kern = gru_big_tagged_kernel<G, MT>;
         if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), GP_LDS_BYTES)) return rc_lds;
+        if (!persistent_grid_fits(reinterpret_cast<const void *>(kern), 2 * GP_WG * n_sets, m->num_cus)) return kPersistentDoesNotFit;
         SEDMI_CHECK_HIP(hipMemsetAsync(sc.hx, 0xff, static_cast<size_t>(gt_hx_index(MT, 2, 0, n_groups, 0, 0)) * 16, s));
         hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
                            reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words,
@@ -1858,6 +1884,7 @@ int launch_gru_persistent(const sedmi_shake_rcnn *m, long n, int T4, int n_group
     }
     auto kern = gru_big_persistent_kernel<G, MT>;
     if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), GP_LDS_BYTES)) return rc_lds;
+    if (!persistent_grid_fits(reinterpret_cast<const void *>(kern), 2 * GP_WG * n_sets, m->num_cus)) return kPersistentDoesNotFit;
     hipLaunchKernelGGL(kern, dim3(GP_WG, 2, static_cast<unsigned>(n_sets)), dim3(512), GP_LDS_BYTES, s, sc.gi,
                        reinterpret_cast<const uint4 *>(m->d_whh), m->whh_oscale, m->d_bhn, sc.rec, sc.hx, sc.sync_words, n,
                        T4, n_groups, n_sets, gru_spin_limit());
@@ -1880,12 +1907,13 @@ int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, c
     if (m->recurrence == SEDMI_RECURRENCE_AUTO && gru_persistent_wanted() && G <= GP_MAX_G &&
         2 * GP_WG * n_sets <= m->num_cus && T4 >= 2) {
         sedmi::ProfileScope prof("shake_gru_persistent", s, 2.0 * rows * 2 * 3 * GB_H * GB_H, 4.0 * rows * (6144.0 + 2048.0));
-        if (MT == 1) return launch_gru_persistent<1, 1>(m, n, T4, n_groups, n_sets, sc, s);
-        switch (G) {
-            case 1: return launch_gru_persistent<1, 2>(m, n, T4, n_groups, n_sets, sc, s);
-            case 2: return launch_gru_persistent<2, 2>(m, n, T4, n_groups, n_sets, sc, s);
-            default: return launch_gru_persistent<3, 2>(m, n, T4, n_groups, n_sets, sc, s);
-        }
+        int prc;
+        if (MT == 1) prc = launch_gru_persistent<1, 1>(m, n, T4, n_groups, n_sets, sc, s);
+        else if (G == 1) prc = launch_gru_persistent<1, 2>(m, n, T4, n_groups, n_sets, sc, s);
+        else if (G == 2) prc = launch_gru_persistent<2, 2>(m, n, T4, n_groups, n_sets, sc, s);
+        else prc = launch_gru_persistent<3, 2>(m, n, T4, n_groups, n_sets, sc, s);
+        if (prc != kPersistentDoesNotFit) return prc;
+        // the runtime says the grid cannot be resident at once on this device: one launch per step below
     }
     SEDMI_CHECK_HIP(hipMemsetAsync(sc.h0, 0, sizeof(float) * 2 * n * GB_H, s));
     const size_t lds = 4 * 2 * 32 * ((GB_H / 4) * 2 + 16);
