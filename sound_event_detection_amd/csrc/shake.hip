@@ -41,6 +41,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 namespace {
 
@@ -159,6 +160,13 @@ struct Conv2dGeom {
     static_assert(CIN % CCH == 0 && CCH % 16 == 0 && N % 32 == 0 && LDS_BYTES <= 80 * 1024, "bad conv2d geometry");
 };
 
+// v_permlane16_swap: rows 1 and 3 (lanes 16-31, 48-63) of `a` change places with rows 0 and 2 of `b`.  Through inline
+// assembly: this toolchain's __builtin_amdgcn_permlane16_swap returns its first result twice.  The waits on either
+// side cover the instruction's read-after-write distances, which the compiler does not track through an asm.
+__device__ __forceinline__ void swap_rows16(float &a, float &b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 // position p (0..255) of a tile -> (row, col) inside the tile; a pooling window is a run of
 // consecutive p, hence of consecutive accumulator registers of one lane
 template <int PH, int PW>
@@ -228,39 +236,85 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
     }
     const uint4 *bp = wp + (col32 + 32 * wn) * 2 + half;
 
-    constexpr int POS = (TR + 2) * G::TW;
-    constexpr int STAGE_F4 = POS * (CCH / 4);
-    constexpr int NLD = (STAGE_F4 + 255) / 256;
+    // Staging map.  A 16-byte piece of the tile's (TR + 2) x 34 input positions is fetched by the same thread in every
+    // pass and every chunk: columns 0..31 of RSTEP rows per pass ("main"), then the two rightmost halo columns of all
+    // rows in one more pass ("edge").  Everything that depends on the thread is computed once per tile -- a load costs
+    // one add, an LDS store none (its offset is an immediate).  The clip's input sits behind a buffer descriptor:
+    // rows above and below the image come out of its range check as zero (the conv's padding), columns left and right
+    // of the image get an offset that stays out of range whatever is added to it.
+    constexpr int Q = CCH / 4;                          // pieces per position and chunk
+    constexpr int ROWS = TR + 2;
+    constexpr int RSTEP = 256 / (C2_TC * Q);            // rows per main pass
+    constexpr int NMAIN = ROWS / RSTEP, NEDGE = 2 * Q * ROWS, NLD = NMAIN + 1;
+    static_assert((Q == 4 || Q == 8) && ROWS % RSTEP == 0 && NEDGE <= 256, "staging map");
+    constexpr unsigned kOutOfRange = 0x80000000u;       // + (rows + chunks) of a tile stays below 2^32 (checked by the host)
     using f32x4v = __attribute__((ext_vector_type(4))) float;
     f32x4v v[NLD];
-    // the clip's input through a buffer descriptor: positions outside the image get an out-of-range offset and
-    // read as zero (the conv's padding) without a branch
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xc), 0, H * W * CIN * 4, 0x00020000);
+    const unsigned rowb = static_cast<unsigned>(W) * CIN * 4;
+    unsigned g_main, g_edge;
+    int l_main, l_edge;
+    {
+        const int q = tid % Q, col = (tid / Q) % C2_TC, rsel = tid / (Q * C2_TC);
+        const int xx = tx0 - 1 + col;
+        g_main = (xx >= 0 && xx < W) ? static_cast<unsigned>((ty0 - 1 + rsel) * W + xx) * (CIN * 4) + q * 16 : kOutOfRange;
+        l_main = (rsel * G::TW + col) * G::PSB + q * 8;
+        const int er = tid / (2 * Q), ec = (tid / Q) & 1, ex = tx0 + C2_TC - 1 + ec;
+        g_edge = (tid < NEDGE && ex < W) ? static_cast<unsigned>((ty0 - 1 + er) * W + ex) * (CIN * 4) + q * 16 : kOutOfRange;
+        l_edge = (er * G::TW + C2_TC + ec) * G::PSB + q * 8;
+    }
     auto load_chunk = [&](int c) {
+        const unsigned co = static_cast<unsigned>(c) * (CCH * 4);
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j;
-            const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
-            const int yy = ty0 - 1 + pos / G::TW, xx = tx0 - 1 + pos % G::TW;
-            const bool ok = i < STAGE_F4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const unsigned off = ok ? static_cast<unsigned>(((yy * W + xx) * CIN + c * CCH + ch) * 4) : 0xfffffff0u;
-            v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
-        }
+        for (int j = 0; j < NMAIN; ++j)
+            v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  xrs, static_cast<int>(g_main + (co + j * RSTEP * rowb)), 0, 0));
+        v[NMAIN] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(g_edge + co), 0, 0));
+    };
+    // MODE_GATE with one staged chunk: the conv input at the lane's own output positions (the factor of the gate) is
+    // requested here, behind the tile's staging loads and from the same cache lines, and waits in registers for the
+    // epilogue: one load per value instead of two 16-bit LDS reads, two conversions and an add.  A position outside
+    // the image reads zero (rows) or a neighbour's value (columns); neither reaches a stored output.
+    // position of register r relative to the lane's register 0 (tile_pos of consecutive positions), and the pooled
+    // column of the window that ends in register r relative to the lane's first window
+    auto d_ty = [](int r) { return PH == 2 ? (r & 3) >> 1 : 0; };
+    auto d_tx = [](int r) { return PH == 2 ? 4 * (r >> 2) + (r & 1) : 8 * (r >> 2) + (r & 3); };
+    auto d_xo = [](int r) { return PH == 2 ? 2 * (r >> 2) : 4 * (r >> 2) + ((r & 3) >> 1); };
+    constexpr bool UC_EARLY = MODE == MODE_GATE && G::NCHUNK == 1;
+    constexpr int UC_NT = CO >= 32 ? CO / 32 / WN : 1, UC_R = CO == 16 ? 8 : 16;
+    float ucv[UC_EARLY ? MT * UC_NT * UC_R : 1];
+    auto load_uc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < UC_NT; ++nt) {
+                int ty, tx;
+                tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half + (CO == 16 ? 16 * (col32 >> 4) : 0), ty, tx);
+                const int ch = CO == 16 ? (col32 & 15) : colof(nt);
+                const unsigned gbase = static_cast<unsigned>(((ty0 + ty) * W + tx0 + tx) * CIN + ch) * 4u;
+#pragma unroll
+                for (int r = 0; r < UC_R; ++r)
+                    ucv[(mt * UC_NT + nt) * UC_R + r] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(
+                                   xrs, static_cast<int>(gbase + d_ty(r) * rowb + d_tx(r) * CIN * 4), 0, 0));
+            }
     };
     for (int c = 0; c < G::NCHUNK; ++c) {
         load_chunk(c);
+        if constexpr (UC_EARLY) load_uc();
         if (c) __syncthreads();
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j;
-            const int pos = i / (CCH / 4), ch = (i - pos * (CCH / 4)) * 4;
             uint2 hi, lo;
             split2_f16(v[j][0], v[j][1], hi.x, lo.x);
             split2_f16(v[j][2], v[j][3], hi.y, lo.y);
-            if (i < STAGE_F4) {
-                *reinterpret_cast<uint2 *>(plane_h + pos * G::PSB + ch * 2) = hi;
-                *reinterpret_cast<uint2 *>(plane_l + pos * G::PSB + ch * 2) = lo;
+            if (j < NMAIN) {
+                *reinterpret_cast<uint2 *>(plane_h + l_main + j * RSTEP * G::TW * G::PSB) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + l_main + j * RSTEP * G::TW * G::PSB) = lo;
+            } else if (tid < NEDGE) {
+                *reinterpret_cast<uint2 *>(plane_h + l_edge) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + l_edge) = lo;
             }
         }
         __syncthreads();
@@ -371,105 +425,118 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                 }
             }
     } else if constexpr (MODE == MODE_GLU) {
+        // An m-tile is one row of the tile and a lane's 16 registers are 16 of its columns: one offset per m-tile and
+        // lane, the registers' distances are immediates.  Rows below the image fall out of the descriptor's range;
+        // columns right of it (only in a clip whose width is no multiple of the tile's) are sent there.
+        static_assert(PH == 1 && PW == 1, "the GLU kernels do not pool");
         float *yc = y + clip * static_cast<long>(H) * W * CO;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yc, 0, H * W * CO * 4, 0x00020000);
+        const int xlim = W - tx0 - 4 * half;              // register r holds column acc_row(r, 0) + 4 * half
+        auto store_all = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned base =
+                    static_cast<unsigned>(((ty0 + MT * wm + mt) * W + tx0 + 4 * half) * CO + col32 + 32 * wn) * 4u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int ty, tx;
-                tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
-                const int yy = ty0 + ty, xx = tx0 + tx;
-                if (yy < H && xx < W) {
+                for (int r = 0; r < 16; ++r)
 #pragma unroll
-                    for (int nt = 0; nt < NT / 2; ++nt)
-                        yc[(static_cast<long>(yy) * W + xx) * CO + colof(nt)] =
+                    for (int nt = 0; nt < NT / 2; ++nt) {
+                        const float val =
                             acc[mt][nt][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt + NT / 2][r]));
-                }
+                        unsigned off = base + (acc_row(r, 0) * CO + 32 * WN * nt) * 4;
+                        if (!FULL && acc_row(r, 0) >= xlim) off = 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, static_cast<int>(off), 0, 0);
+                    }
             }
+        };
+        if (tx0 + C2_TC <= W) store_all(std::true_type{});
+        else store_all(std::false_type{});
     } else {
+        static_assert(CO == 16 || CO % (32 * WN) == 0, "channels per wave");
         constexpr int NTC = CO >= 32 ? CO / 32 / WN : 1;   // channel tiles per wave after mixing the branches
         constexpr int WIN = PH * PW;
+        static_assert((PH == 2 && PW == 2) || (PH == 1 && PW == 2), "pooling windows are runs of 4 or 2 registers");
         const int Ho = H / PH, Wo = W / PW;
         float *yc = y + clip * static_cast<long>(Ho) * Wo * CO;
-        const bool lane_ok = CO >= 32 || col32 < CO;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yc, 0, Ho * Wo * CO * 4, 0x00020000);
         if constexpr (CO == 16) {
             // One 32-column tile holds both branches: channel c is column c (branch 1) and column c + 16 (branch
             // 2), i.e. lanes L and L + 16 hold the two branch values of the same 16 positions.  The pair shares the
-            // work: the low lane finishes the first 8 positions (two pooling windows), the high lane the other 8,
-            // after one exchange of the 8 values the partner needs.
+            // work: the low lane finishes the positions of registers 0-7 (two pooling windows), the high lane those of
+            // registers 8-15.  One row swap per register pair (k, k + 8) leaves branch 1 of the lane's position in
+            // the first register and branch 2 in the second, in both lanes.
             static_assert(G::NCHUNK == 1 && WN == 1 && PH == 2 && PW == 2, "the 16-channel gate assumes one staged chunk and 2x2 pooling");
             const int hi16 = col32 >> 4, ch = col32 & 15;
             const float b2s = s2[ch], b2t = t2[ch];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                float mine[8], theirs[8];
+                float z[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float lo = acc[mt][0][k], hi = acc[mt][0][k + 8];
-                    mine[k] = hi16 ? hi : lo;
-                    theirs[k] = __shfl_xor(hi16 ? lo : hi, 16);
+                    float b1 = acc[mt][0][k], b2 = acc[mt][0][k + 8];
+                    swap_rows16(b1, b2);
+                    z[k] = b1 + b2;
                 }
                 // position of value k: pb + (k & 3) + 8 * (k >> 2) with pb a multiple of 4 (acc_row(k + 8) = acc_row(k) + 16)
                 int ty, tx;
                 tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half + 16 * hi16, ty, tx);
-                const char *ph0 = plane_h + ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
-                const char *pl0 = plane_l + ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
+                const unsigned obase = static_cast<unsigned>((((ty0 + ty) / PH) * Wo + (tx0 + tx) / PW) * CO + ch) * 4u;
 #pragma unroll
                 for (int win = 0; win < 2; ++win) {
                     float sum = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int k = 4 * win + q;
-                        const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mine[k] + theirs[k]));
-                        const int poff = (((q >> 1) & 1) * G::TW + (q & 1) + 4 * win) * G::PSB;
-                        const float uc = static_cast<float>(*reinterpret_cast<const _Float16 *>(ph0 + poff)) +
-                                         static_cast<float>(*reinterpret_cast<const _Float16 *>(pl0 + poff));
-                        sum += fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
+                        const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[4 * win + q]));
+                        sum += fmaxf(fmaf(ucv[mt * 8 + 4 * win + q] * gate, b2s, b2t), 0.f);
                     }
-                    const int yo = (ty0 + ty) / PH, xo = (tx0 + tx + 4 * win) / PW;
-                    if (yo < Ho && xo < Wo) yc[(static_cast<long>(yo) * Wo + xo) * CO + ch] = sum * 0.25f;
+                    unsigned off = obase + d_xo(4 * win) * CO * 4;
+                    if (tx0 + tx + d_tx(4 * win) + 1 >= W) off = 0x80000000u;        // the window's last column is outside
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * 0.25f), yrs, static_cast<int>(off), 0, 0);
                 }
             }
         } else {
+            auto gate_all = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {
-            const int ch = colof(nt);
-            const float b2s = lane_ok ? s2[ch] : 0.f, b2t = lane_ok ? t2[ch] : 0.f;
+                for (int nt = 0; nt < NTC; ++nt) {
+                    const int ch = colof(nt);
+                    const float b2s = s2[ch], b2t = t2[ch];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float sum = 0.f;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        int ty, tx;                                   // the lane's register 0
+                        tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half, ty, tx);
+                        const int xlim = W - tx0 - tx;                // columns d_tx < xlim exist
+                        const unsigned obase = static_cast<unsigned>((((ty0 + ty) / PH) * Wo + (tx0 + tx) / PW) * CO + ch) * 4u;
+                        // the centre input: requested before the main loop when the kernel stages one chunk, else here
+                        float ucl[16];
+                        if constexpr (!UC_EARLY) {
+                            const unsigned gbase = static_cast<unsigned>(((ty0 + ty) * W + tx0 + tx) * CIN + ch) * 4u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float z1 = acc[mt][nt][r];
-                    float z2;
-                    if constexpr (CO >= 32) z2 = acc[mt][nt + NTC][r];
-                    else z2 = __shfl_xor(z1, 16);          // branch 2 of channel c lives in column c + 16
-                    const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z1 + z2));
-                    int ty, tx;
-                    tile_pos<PH, PW>(PWV * wm + 32 * mt + acc_row(r, half), ty, tx);
-                    const int yy = ty0 + ty, xx = tx0 + tx;
-                    float uc = 0.f;
-                    if constexpr (G::NCHUNK == 1) {
-                        // the centre input is still in the staged planes (hi + lo restores it to 2^-22; positions
-                        // outside the image were staged as zero)
-                        const int poff = ((ty + 1) * G::TW + tx + 1) * G::PSB + ch * 2;
-                        if (lane_ok)
-                            uc = static_cast<float>(*reinterpret_cast<const _Float16 *>(plane_h + poff)) +
-                                 static_cast<float>(*reinterpret_cast<const _Float16 *>(plane_l + poff));
-                    } else {
-                        if (lane_ok && yy < H && xx < W) uc = xc[(static_cast<long>(yy) * W + xx) * CIN + ch];
-                    }
-                    const float val = fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
-                    sum += val;
-                    if ((r % WIN) == WIN - 1) {
-                        const int yo = yy / PH, xo = xx / PW;
-                        if (lane_ok && yo < Ho && xo < Wo)
-                            yc[(static_cast<long>(yo) * Wo + xo) * CO + ch] = sum * (1.0f / WIN);
-                        sum = 0.f;
+                            for (int r = 0; r < 16; ++r)
+                                ucl[r] = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               xrs, static_cast<int>(gbase + d_ty(r) * rowb + d_tx(r) * CIN * 4), 0, 0));
+                        }
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt][r] + acc[mt][nt + NTC][r]));
+                            const float uc = UC_EARLY ? ucv[(mt * UC_NT + nt) * 16 + r] : ucl[r];
+                            sum += fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
+                            if ((r % WIN) == WIN - 1) {
+                                unsigned off = obase + d_xo(r) * CO * 4;
+                                if (!FULL && d_tx(r) >= xlim) off = 0x80000000u;   // r is the window's last column
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * (1.0f / WIN)), yrs,
+                                                                      static_cast<int>(off), 0, 0);
+                                sum = 0.f;
+                            }
+                        }
                     }
                 }
-            }
-        }
+            };
+            if (tx0 + C2_TC <= W) gate_all(std::true_type{});
+            else gate_all(std::false_type{});
         }
     }
 }
@@ -1750,7 +1817,11 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
     using G = Conv2dGeom<CIN, N, CCH, TR>;
     const int tiles_x = static_cast<int>(MODE == MODE_POOL_W5 ? sedmi::ceil_div(W - 4, C2_TC - 4) : sedmi::ceil_div(W, C2_TC));
     const int tiles_y = static_cast<int>(sedmi::ceil_div(H, TR));
-    if (4.0 * H * W * CIN >= 2147483648.0) return SEDMI_EINVAL;      // one clip's input is addressed with 32-bit offsets
+    // one clip's input and output are addressed with 32-bit offsets, and an offset sent out of range (2^31) must stay
+    // below 2^32 when the rows of a tile are added to it
+    const double out_ch = MODE == MODE_GLU ? N / 2.0 : MODE == MODE_GATE ? N / 2.0 / (PH * PW) : 0.0;   // the other modes store through pointers
+    if (4.0 * (H + TR + 2) * W * std::max<double>(CIN, out_ch) >= 2147483648.0)
+        return sedmi::set_error(SEDMI_EINVAL, "%s: a clip of %d x %d positions does not fit 32-bit byte offsets", name, H, W);
     auto kern = conv2d_split_kernel<CIN, N, CCH, MODE, PH, PW, WN, TR>;
     if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), G::LDS_BYTES)) return rc_lds;
     const double pos = static_cast<double>(n) * H * W;
