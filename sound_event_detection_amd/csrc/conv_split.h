@@ -243,38 +243,33 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const int ncol = wn * 32 * NT + col32;
     const uint4 *bp = wp + ncol * 2 + half;
 
+    // Staging map: 256 threads fetch RPJ whole rows of a chunk per pass, a thread the same 16-byte piece of its row
+    // in every pass and chunk, so everything that depends on the thread is computed once per tile: a load costs one
+    // add, an LDS store none (its offset is an immediate).  All of a thread's loads of a chunk are issued before the
+    // first one is consumed, and the loads of chunk c + 1 before the MFMA loop of chunk c: only the first chunk's
+    // latency is exposed.  The clip's input sits behind a buffer descriptor that spans exactly the clip: rows above
+    // it (negative offsets wrap to huge unsigned ones) and below it fall outside and read as zero -- the conv's
+    // padding -- with no branch and no 64-bit address arithmetic.
     constexpr int ROW_F4 = W * CCH / 4;
-    constexpr int STAGE_F4 = (G::TH + 2) * ROW_F4;
-    constexpr int NLD = (STAGE_F4 + 255) / 256;
-    // all of a thread's loads of a chunk are issued before the first one is consumed, and the loads of
-    // chunk c+1 are issued before the MFMA loop of chunk c: only the first chunk's latency is exposed
-    // Two ways to fetch the rows.  Through a buffer descriptor that spans exactly this clip's input, rows above
-    // the clip (negative offsets wrap to huge unsigned ones) and below it fall outside and read as zero -- the
-    // conv's padding -- with no branch and no 64-bit address arithmetic per load: 2-3 % faster for the blocks
-    // that stage several chunks per tile.  The single-chunk blocks and the two-column block measured 2-3 %
-    // faster with plain predicated loads, so they keep those.
-    constexpr bool BUF_STAGE = G::NCHUNK > 1 && W > 2;
+    static_assert(ROW_F4 <= 256 && 256 % ROW_F4 == 0, "a pass covers whole rows");
+    constexpr int RPJ = 256 / ROW_F4, ROWS = G::TH + 2;
+    constexpr int NLD = (ROWS + RPJ - 1) / RPJ;
     using f32x4v = __attribute__((ext_vector_type(4))) float;
     f32x4v v[NLD];
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xc), 0, H * W * CIN * 4, 0x00020000);
+    const int rr0 = tid / ROW_F4, e0 = (tid % ROW_F4) * 4, w0 = e0 / CCH, ch0 = e0 % CCH;
+    const unsigned g_base = static_cast<unsigned>(((h0 - 1 + rr0) * W + w0) * CIN + ch0) * 4u;
+    const int l_base = (rr0 * G::TW + 1 + w0) * G::PSB + ch0 * 2;
+    // the last pass may reach past the staged rows: those threads read nothing (an offset out of range) and write nothing
+    constexpr bool RAGGED = NLD * RPJ > ROWS;
+    const bool in_last = !RAGGED || rr0 < ROWS - (NLD - 1) * RPJ;
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j;
-            const int rr = i / ROW_F4, e = (i - rr * ROW_F4) * 4;
-            const int w = e / CCH, ch = e - w * CCH;
-            const int hr = h0 - 1 + rr;
-            if constexpr (BUF_STAGE) {
-                unsigned off = ((static_cast<unsigned>(hr) * W + w) * CIN + c * CCH + ch) * 4u;
-                // threads past the staged rows (last trip only) are sent out of range instead of reading rows nobody uses
-                if (256 * (j + 1) > STAGE_F4 && i >= STAGE_F4) off = 0xfffffff0u;
-                v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
-            } else {
-                v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-                if (i < STAGE_F4 && hr >= 0 && hr < H)
-                    v[j] = *reinterpret_cast<const f32x4v *>(xc + (static_cast<long>(hr) * W + w) * CIN + c * CCH + ch);
-            }
+            unsigned off = g_base + static_cast<unsigned>(c * CCH * 4 + j * RPJ * W * CIN * 4);
+            if (RAGGED && j == NLD - 1 && !in_last) off = 0xfffffff0u;
+            v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
         }
     };
     load_chunk(0);
@@ -284,16 +279,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         SPLIT_TICK(1);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = tid + 256 * j;
-            const int rr = i / ROW_F4, e = (i - rr * ROW_F4) * 4;
-            const int w = e / CCH, ch = e - w * CCH;
             uint2 hi, lo;
             split2_f16(v[j][0], v[j][1], hi.x, lo.x);
             split2_f16(v[j][2], v[j][3], hi.y, lo.y);
-            if (i < STAGE_F4) {
-                const int off = (rr * G::TW + 1 + w) * G::PSB + ch * 2;
-                *reinterpret_cast<uint2 *>(plane_h + off) = hi;
-                *reinterpret_cast<uint2 *>(plane_l + off) = lo;
+            if (!RAGGED || j < NLD - 1 || in_last) {
+                *reinterpret_cast<uint2 *>(plane_h + l_base + j * RPJ * G::TW * G::PSB) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + l_base + j * RPJ * G::TW * G::PSB) = lo;
             }
         }
         __syncthreads();
