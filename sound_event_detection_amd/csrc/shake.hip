@@ -41,7 +41,6 @@
 #include <map>
 #include <mutex>
 #include <string>
-#include <type_traits>
 
 namespace {
 
@@ -426,32 +425,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
             }
     } else if constexpr (MODE == MODE_GLU) {
         // An m-tile is one row of the tile and a lane's 16 registers are 16 of its columns: one offset per m-tile and
-        // lane, the registers' distances are immediates.  Rows below the image fall out of the descriptor's range;
-        // columns right of it (only in a clip whose width is no multiple of the tile's) are sent there.
+        // lane, the registers' distances are immediates.  Rows below the image fall out of the descriptor's range; the
+        // width is a whole number of tiles (checked by the host).
         static_assert(PH == 1 && PW == 1, "the GLU kernels do not pool");
         float *yc = y + clip * static_cast<long>(H) * W * CO;
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yc, 0, H * W * CO * 4, 0x00020000);
-        const int xlim = W - tx0 - 4 * half;              // register r holds column acc_row(r, 0) + 4 * half
-        auto store_all = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const unsigned base =
-                    static_cast<unsigned>(((ty0 + MT * wm + mt) * W + tx0 + 4 * half) * CO + col32 + 32 * wn) * 4u;
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned base =
+                static_cast<unsigned>(((ty0 + MT * wm + mt) * W + tx0 + 4 * half) * CO + col32 + 32 * wn) * 4u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-                    for (int nt = 0; nt < NT / 2; ++nt) {
-                        const float val =
-                            acc[mt][nt][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt + NT / 2][r]));
-                        unsigned off = base + (acc_row(r, 0) * CO + 32 * WN * nt) * 4;
-                        if (!FULL && acc_row(r, 0) >= xlim) off = 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, static_cast<int>(off), 0, 0);
-                    }
-            }
-        };
-        if (tx0 + C2_TC <= W) store_all(std::true_type{});
-        else store_all(std::false_type{});
+                for (int nt = 0; nt < NT / 2; ++nt) {
+                    const float val =
+                        acc[mt][nt][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt + NT / 2][r]));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
+                                                          static_cast<int>(base + (acc_row(r, 0) * CO + 32 * WN * nt) * 4), 0, 0);
+                }
+        }
     } else {
         static_assert(CO == 16 || CO % (32 * WN) == 0, "channels per wave");
         constexpr int NTC = CO >= 32 ? CO / 32 / WN : 1;   // channel tiles per wave after mixing the branches
@@ -490,53 +482,44 @@ __global__ __launch_bounds__(256, 2) void conv2d_split_kernel(
                         const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[4 * win + q]));
                         sum += fmaxf(fmaf(ucv[mt * 8 + 4 * win + q] * gate, b2s, b2t), 0.f);
                     }
-                    unsigned off = obase + d_xo(4 * win) * CO * 4;
-                    if (tx0 + tx + d_tx(4 * win) + 1 >= W) off = 0x80000000u;        // the window's last column is outside
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * 0.25f), yrs, static_cast<int>(off), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * 0.25f), yrs,
+                                                          static_cast<int>(obase + d_xo(4 * win) * CO * 4), 0, 0);
                 }
             }
         } else {
-            auto gate_all = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt) {
-                    const int ch = colof(nt);
-                    const float b2s = s2[ch], b2t = t2[ch];
+            for (int nt = 0; nt < NTC; ++nt) {
+                const int ch = colof(nt);
+                const float b2s = s2[ch], b2t = t2[ch];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        int ty, tx;                                   // the lane's register 0
-                        tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half, ty, tx);
-                        const int xlim = W - tx0 - tx;                // columns d_tx < xlim exist
-                        const unsigned obase = static_cast<unsigned>((((ty0 + ty) / PH) * Wo + (tx0 + tx) / PW) * CO + ch) * 4u;
-                        // the centre input: requested before the main loop when the kernel stages one chunk, else here
-                        float ucl[16];
-                        if constexpr (!UC_EARLY) {
-                            const unsigned gbase = static_cast<unsigned>(((ty0 + ty) * W + tx0 + tx) * CIN + ch) * 4u;
+                for (int mt = 0; mt < MT; ++mt) {
+                    int ty, tx;                                   // the lane's register 0
+                    tile_pos<PH, PW>(PWV * wm + 32 * mt + 4 * half, ty, tx);
+                    const unsigned obase = static_cast<unsigned>((((ty0 + ty) / PH) * Wo + (tx0 + tx) / PW) * CO + ch) * 4u;
+                    // the centre input: requested before the main loop when the kernel stages one chunk, else here
+                    float ucl[16];
+                    if constexpr (!UC_EARLY) {
+                        const unsigned gbase = static_cast<unsigned>(((ty0 + ty) * W + tx0 + tx) * CIN + ch) * 4u;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                ucl[r] = __builtin_bit_cast(
-                                    float, __builtin_amdgcn_raw_buffer_load_b32(
-                                               xrs, static_cast<int>(gbase + d_ty(r) * rowb + d_tx(r) * CIN * 4), 0, 0));
-                        }
-                        float sum = 0.f;
+                        for (int r = 0; r < 16; ++r)
+                            ucl[r] = __builtin_bit_cast(
+                                float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           xrs, static_cast<int>(gbase + d_ty(r) * rowb + d_tx(r) * CIN * 4), 0, 0));
+                    }
+                    float sum = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt][r] + acc[mt][nt + NTC][r]));
-                            const float uc = UC_EARLY ? ucv[(mt * UC_NT + nt) * 16 + r] : ucl[r];
-                            sum += fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
-                            if ((r % WIN) == WIN - 1) {
-                                unsigned off = obase + d_xo(r) * CO * 4;
-                                if (!FULL && d_tx(r) >= xlim) off = 0x80000000u;   // r is the window's last column
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * (1.0f / WIN)), yrs,
-                                                                      static_cast<int>(off), 0, 0);
-                                sum = 0.f;
-                            }
+                    for (int r = 0; r < 16; ++r) {
+                        const float gate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[mt][nt][r] + acc[mt][nt + NTC][r]));
+                        const float uc = UC_EARLY ? ucv[(mt * UC_NT + nt) * 16 + r] : ucl[r];
+                        sum += fmaxf(fmaf(uc * gate, b2s, b2t), 0.f);
+                        if ((r % WIN) == WIN - 1) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum * (1.0f / WIN)), yrs,
+                                                                  static_cast<int>(obase + d_xo(r) * CO * 4), 0, 0);
+                            sum = 0.f;
                         }
                     }
                 }
-            };
-            if (tx0 + C2_TC <= W) gate_all(std::true_type{});
-            else gate_all(std::false_type{});
+            }
         }
     }
 }
@@ -1819,6 +1802,9 @@ int launch_conv2d(const char *name, const uint16_t *wp, const float *es, const f
     const int tiles_y = static_cast<int>(sedmi::ceil_div(H, TR));
     // one clip's input and output are addressed with 32-bit offsets, and an offset sent out of range (2^31) must stay
     // below 2^32 when the rows of a tile are added to it
+    // (an odd last row of a pooling kernel has no output: its stores fall out of the output descriptor's range)
+    if ((MODE == MODE_GLU || MODE == MODE_GATE) && W % C2_TC)
+        return sedmi::set_error(SEDMI_EINVAL, "%s: a width of %d is not a whole number of %d-column tiles", name, W, C2_TC);
     const double out_ch = MODE == MODE_GLU ? N / 2.0 : MODE == MODE_GATE ? N / 2.0 / (PH * PW) : 0.0;   // the other modes store through pointers
     if (4.0 * (H + TR + 2) * W * std::max<double>(CIN, out_ch) >= 2147483648.0)
         return sedmi::set_error(SEDMI_EINVAL, "%s: a clip of %d x %d positions does not fit 32-bit byte offsets", name, H, W);

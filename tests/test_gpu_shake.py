@@ -70,6 +70,20 @@ def test_ragged_batch_vs_oracle(model):
     np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
 
 
+@pytest.mark.parametrize("T", [7, 10, 13])
+def test_frame_counts_that_leave_an_odd_row_to_a_pooling_stage_vs_oracle(model, T):
+    # AvgPool2d floors (models.py:155-180): 7 -> 3 -> 1, 10 -> 5 -> 2, 13 -> 6 -> 3; the last odd row of a stage has no
+    # output but is still a neighbour of the row above it in that stage's 3x3 convs
+    from oracle import shake
+    sd = synth.synth_shake_state_dict(synth.shake_rcnn_state_dict_spec(10), 0)
+    x = torch.from_numpy(synth.synth_shake_feats(7, 3, T))
+    al = [0.2, 0.55, 0.8]
+    want = shake.shake_rcnn_forward(sd, x, al).numpy()
+    got = model(x.cuda(), al).cpu().numpy()
+    assert got.shape == want.shape == (3, T // 4, 10)
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
+
+
 def test_clips_are_independent(model):
     x = torch.from_numpy(synth.synth_shake_feats(6, 3, 16)).cuda()
     al = [0.3, 0.6, 0.9]
