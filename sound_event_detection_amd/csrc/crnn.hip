@@ -1086,10 +1086,18 @@ __global__ __launch_bounds__(256, 2) void head_small_kernel(const float *__restr
     }
 }
 
+// Clips per pass through the conv stack (bounds the scratch), and clips per inner pass through blocks 2-4.  Measured
+// on 4096 clips: the blocks with the largest activations per FLOP (2, 3) run fastest when their input was written
+// just before (512-clip passes: part of it is still in the memory-side cache; with 1024 and more they lose 2-4 %),
+// the light kernels (blocks 0, 1, 5, 6) when a launch is long (fewer launches, smaller tails: 4-6 % at 1024).
 #ifndef SEDMI_CNN_CHUNK
-#define SEDMI_CNN_CHUNK 512
+#define SEDMI_CNN_CHUNK 1024
 #endif
-constexpr int kCnnChunk = SEDMI_CNN_CHUNK;     // clips per pass through the conv stack (bounds the scratch)
+#ifndef SEDMI_CNN_SUB
+#define SEDMI_CNN_SUB 512
+#endif
+constexpr int kCnnChunk = SEDMI_CNN_CHUNK, kCnnSub = SEDMI_CNN_SUB;
+static_assert(kCnnSub > 0 && kCnnChunk % kCnnSub == 0, "inner passes tile the outer one");
 
 }  // namespace
 
@@ -1213,9 +1221,15 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
         int rc;
         if (m->precision == SEDMI_PRECISION_SPLIT_F16) {
             if ((rc = launch_conv_split<16, 32, 64, 4, 2, 16>(m, 1, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB, actA, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<64, 128, 16, CONV_WM, CONV_MT, 32>(m, 3, actA, actB, nc, Tp, s))) return rc;
-            if ((rc = launch_conv_split<128, 128, 8, CONV_WM, CONV_MT, 32>(m, 4, actB, actA, nc, Tp, s))) return rc;
+            // blocks 2-4 one inner pass at a time, each reading what the one before it has just written (a clip's
+            // activations are Tp x 1024 floats behind blocks 1-3 and Tp x 512 behind block 4)
+            const long sub = kCnnSub;
+            for (long s0 = 0; s0 < nc; s0 += sub) {
+                const long ns = std::min<long>(sub, nc - s0);
+                if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB + s0 * Tp * 1024, actA + s0 * Tp * 1024, ns, Tp, s))) return rc;
+                if ((rc = launch_conv_split<64, 128, 16, CONV_WM, CONV_MT, 32>(m, 3, actA + s0 * Tp * 1024, actB + s0 * Tp * 1024, ns, Tp, s))) return rc;
+                if ((rc = launch_conv_split<128, 128, 8, CONV_WM, CONV_MT, 32>(m, 4, actB + s0 * Tp * 1024, actA + s0 * Tp * 512, ns, Tp, s))) return rc;
+            }
             if ((rc = launch_conv_split<128, 128, 4, CONV_WM, CONV_MT, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;
             if ((rc = launch_conv_split<128, 128, 2, CONV_WM, CONV_MT, 16>(m, 6, actB, seq + c0 * Tp * GRU_H, nc, Tp, s))) return rc;
             continue;
