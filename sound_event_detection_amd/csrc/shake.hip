@@ -1292,16 +1292,73 @@ constexpr int AT_D = 128, AT_KB = 32;
 constexpr int AT_KSB = AT_D * 2 + 16;      // bytes per key row of a K plane
 constexpr int AT_VSB = AT_KB * 2 + 16;     // bytes per dim row of a V^T plane
 
+// One key block of one (clip, head) in the form the attention kernel contracts: K as f16 hi / lo planes [key][dim] and
+// V transposed, [dim][key slot], each row padded as in LDS -- 37 888 contiguous bytes, built once per layer instead of
+// by every one of the T / 128 workgroups that walk the keys.  Keys past the end of the clip are zero rows.
+constexpr int AT_BLOB = 2 * AT_KB * AT_KSB + 2 * AT_D * AT_VSB;
+static_assert(AT_BLOB % 16 == 0, "blocks are copied in 16-byte pieces");
+// Tokens per clip from which the packing pass pays: a block is then walked by 8 or more query tiles.  At 250 tokens
+// (two query tiles) the pass costs more than it saves: 1.7 ms against 1.0 ms per layer-step of 128 clips.
+constexpr int kAttentionPackTokens = 1024;
+__global__ __launch_bounds__(256) void attention_pack_kernel(const float *__restrict__ qkv, uint4 *__restrict__ kv, int T) {
+    __shared__ __attribute__((aligned(16))) char blob[AT_BLOB];
+    char *kh = blob, *kl = kh + AT_KB * AT_KSB, *vth = kl + AT_KB * AT_KSB, *vtl = vth + AT_D * AT_VSB;
+    const int tid = threadIdx.x, head = blockIdx.y, kb0 = blockIdx.x * AT_KB;
+    const float *base = qkv + static_cast<long>(blockIdx.z) * T * 3072 + head * AT_D;
+    for (int i = tid; i < AT_BLOB / 16; i += 256) reinterpret_cast<uint4 *>(blob)[i] = make_uint4(0, 0, 0, 0);   // the padding too
+    __syncthreads();
+    // K: thread -> (key i >> 5, dims 4 (i & 31) .. + 3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j, key = i >> 5, c4 = (i & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb0 + key < T) v = *reinterpret_cast<const float4 *>(base + static_cast<long>(kb0 + key) * 3072 + 1024 + c4);
+        uint2 hi, lo;
+        split2_f16(v.x, v.y, hi.x, lo.x);
+        split2_f16(v.z, v.w, hi.y, lo.y);
+        *reinterpret_cast<uint2 *>(kh + key * AT_KSB + c4 * 2) = hi;
+        *reinterpret_cast<uint2 *>(kl + key * AT_KSB + c4 * 2) = lo;
+    }
+    // V: thread -> (key pair (tid >> 5) + 8 j, dims (tid & 31) + 32 e); key = acc_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h
+    // sits in slot 16 (r >> 3) + 8 h + (r & 7) of V^T's rows (the order in which a lane of the attention kernel holds
+    // its probabilities), an even key and its successor in an even slot and its successor
+    const int vlq = tid & 31, vpair = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 2 * (vpair + 8 * j);
+        const int h = (key >> 2) & 1, r = (key & 3) + 4 * (key >> 3);
+        const int slot = 16 * (r >> 3) + 8 * h + (r & 7);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v0 = 0.f, v1 = 0.f;
+            if (kb0 + key < T) v0 = base[static_cast<long>(kb0 + key) * 3072 + 2048 + vlq + 32 * e];
+            if (kb0 + key + 1 < T) v1 = base[static_cast<long>(kb0 + key + 1) * 3072 + 2048 + vlq + 32 * e];
+            unsigned hi, lo;
+            split2_f16(v0, v1, hi, lo);
+            *reinterpret_cast<unsigned *>(vth + (vlq + 32 * e) * AT_VSB + slot * 2) = hi;
+            *reinterpret_cast<unsigned *>(vtl + (vlq + 32 * e) * AT_VSB + slot * 2) = lo;
+        }
+    }
+    __syncthreads();
+    uint4 *dst = kv + ((static_cast<long>(blockIdx.z) * 8 + head) * gridDim.x + blockIdx.x) * (AT_BLOB / 16);
+    for (int i = tid; i < AT_BLOB / 16; i += 256) dst[i] = reinterpret_cast<const uint4 *>(blob)[i];
+}
+
 // n_splits > 1: the keys are cut into n_splits ranges of whole 32-key blocks and blockIdx.x = query tile * n_splits +
 // range; a workgroup then leaves its normalised partial output in part_o [range][row][1024] and its running maximum
 // and sum in part_ml [range][row][head][2] for attention_merge_kernel (used when the grid would otherwise fill the
 // chip's workgroup slots badly: few long recordings).
+// PACKED: the keys and values come from attention_pack_kernel's blocks (kv) -- staging is a copy into one of two LDS
+// buffers behind the products of the block before, one barrier per block; worth the packing pass when every block is
+// walked by many query tiles (long recordings).  Otherwise every workgroup splits the K / V rows of qkv itself into one
+// LDS buffer, two barriers per block.  The products, their order and their operand bits are the same in both forms.
+template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__restrict__ qkv,   // [clip*T + t][3*1024]
+                                                              const uint4 *__restrict__ kv,    // PACKED: the blocks
                                                               float *__restrict__ out,         // [clip*T + t][1024]
                                                               int T, float scale, int n_splits, float *__restrict__ part_o,
                                                               float *__restrict__ part_ml, long total_rows) {
-    __shared__ __attribute__((aligned(16))) char kh[AT_KB * AT_KSB], kl[AT_KB * AT_KSB];
-    __shared__ __attribute__((aligned(16))) char vth[AT_D * AT_VSB], vtl[AT_D * AT_VSB];
+    extern __shared__ __attribute__((aligned(16))) char at_lds[];       // [kh | kl | vth | vtl], twice if PACKED
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col32 = lane & 31;
     const int head = blockIdx.y;
@@ -1312,7 +1369,9 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
     const int k_begin = split * kb_per * AT_KB, k_end = min(T, k_begin + kb_per * AT_KB);
     const float *base = qkv + row0 * 3072 + head * AT_D;
 
-    // B operand of S^T: this lane's (scaled) query, dims 16 ks + 8 half + 0..7 of k-step ks
+    // B operand of S^T: this lane's query times scale * log2(e) -- the scores come out in the exponent's own unit and
+    // the softmax takes exp2 of differences -- dims 16 ks + 8 half + 0..7 of k-step ks
+    const float qs = scale * 1.4426950408889634f;
     f16x8 qh[AT_D / 16], ql[AT_D / 16];
 #pragma unroll
     for (int ks = 0; ks < AT_D / 16; ++ks) {
@@ -1323,10 +1382,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
             v1 = *reinterpret_cast<const float4 *>(p + 4);
         }
         uint4 h, l;
-        split2_f16(v0.x * scale, v0.y * scale, h.x, l.x);
-        split2_f16(v0.z * scale, v0.w * scale, h.y, l.y);
-        split2_f16(v1.x * scale, v1.y * scale, h.z, l.z);
-        split2_f16(v1.z * scale, v1.w * scale, h.w, l.w);
+        split2_f16(v0.x * qs, v0.y * qs, h.x, l.x);
+        split2_f16(v0.z * qs, v0.w * qs, h.y, l.y);
+        split2_f16(v1.x * qs, v1.y * qs, h.z, l.z);
+        split2_f16(v1.z * qs, v1.w * qs, h.w, l.w);
         qh[ks] = __builtin_bit_cast(f16x8, h);
         ql[ks] = __builtin_bit_cast(f16x8, l);
     }
@@ -1337,8 +1396,31 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
         for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    // the K / V rows of a key block are requested one block ahead (into registers) and split into the LDS planes at
-    // the top of the next iteration: their latency passes under the current block's products.
+    // ---- staging, PACKED: a key block arrives as attention_pack_kernel left it, the four planes in their LDS layout,
+    // 37 888 contiguous bytes behind a buffer descriptor over the (clip, head)'s blocks.  The block after the current
+    // one is requested into registers before the products of the current one and copied into the other LDS buffer
+    // behind them.
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    constexpr int NPC = (AT_BLOB / 16 + 255) / 256;            // 16-byte pieces per thread and block
+    constexpr int LAST = AT_BLOB / 16 - 256 * (NPC - 1);       // threads of the last, partial pass
+    f32x4v st[NPC];                                            // (the form not instantiated leaves its registers unused)
+    const long n_kb = (T + AT_KB - 1) / AT_KB;
+    const __amdgpu_buffer_rsrc_t kvrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(kv + (PACKED ? (static_cast<long>(blockIdx.z) * 8 + head) * n_kb * (AT_BLOB / 16) : 0)), 0,
+        PACKED ? static_cast<int>(n_kb) * AT_BLOB : 0, 0x00020000);
+    auto load_block = [&](int kb0) {
+        const int off = (kb0 / AT_KB) * AT_BLOB + tid * 16;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j)          // the idle threads of the last pass read past the block (never stored)
+            st[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(kvrs, off + j * 4096, 0, 0));
+    };
+    auto store_block = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < NPC - 1; ++j) *reinterpret_cast<f32x4v *>(at_lds + b * AT_BLOB + (tid + 256 * j) * 16) = st[j];
+        if (tid < LAST) *reinterpret_cast<f32x4v *>(at_lds + b * AT_BLOB + (tid + 256 * (NPC - 1)) * 16) = st[NPC - 1];
+    };
+    // ---- staging, not PACKED: the K / V rows of a key block are requested one block ahead (into registers) and split
+    // into the LDS planes at the top of the next iteration: their latency passes under the current block's products.
     // K: thread -> (key i >> 5, dims 4 (i & 31) .. + 3), one 8-byte LDS write per plane, lanes contiguous.
     // V: thread -> (key PAIR (tid >> 5) + 8 j, dims (tid & 31) + 32 e): a pair of neighbouring keys is a pair of
     // neighbouring slots of V^T, so one packed split gives one 32-bit LDS write per dim and plane, and the 32 lanes of
@@ -1365,9 +1447,8 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
                 for (int e = 0; e < 4; ++e) vreg[j][e][kk] = ok ? p[32 * e] : 0.f;
             }
     };
-    load_kv(k_begin);
-    for (int kb0 = k_begin; kb0 < k_end; kb0 += AT_KB) {
-        __syncthreads();
+    auto split_kv = [&]() {
+        char *kh = at_lds, *kl = kh + AT_KB * AT_KSB, *vth = kl + AT_KB * AT_KSB, *vtl = vth + AT_D * AT_VSB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = tid + 256 * j, key = i >> 5, c4 = (i & 31) * 4;
@@ -1392,12 +1473,34 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
                 *reinterpret_cast<unsigned *>(vtl + (vlq + 32 * e) * AT_VSB + slot * 2) = lo;
             }
         }
+    };
+    if constexpr (PACKED) {
+        if (k_begin < k_end) {
+            load_block(k_begin);
+            store_block(0);
+        }
         __syncthreads();
-        if (kb0 + AT_KB < k_end) load_kv(kb0 + AT_KB);
+    } else {
+        load_kv(k_begin);
+    }
+    int buf = 0;
+    for (int kb0 = k_begin; kb0 < k_end; kb0 += AT_KB) {
+        if constexpr (PACKED) {
+            if (kb0 + AT_KB < k_end) load_block(kb0 + AT_KB);
+        } else {
+            __syncthreads();
+            split_kv();
+            __syncthreads();
+            if (kb0 + AT_KB < k_end) load_kv(kb0 + AT_KB);
+        }
+        const char *kh = at_lds + buf * AT_BLOB, *kl = kh + AT_KB * AT_KSB;
+        const char *vth = kl + AT_KB * AT_KSB, *vtl = vth + AT_D * AT_VSB;
         // S^T[key][query]: A row = key col32, B column = query col32
         f32x16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        // (one accumulator: a second one for the odd k-steps, so that no product waits for the one issued just before
+        // it, measured 3 % slower -- 16 more additions, and the other wave of the SIMD fills the gaps anyway)
 #pragma unroll
         for (int ks = 0; ks < AT_D / 16; ++ks) {
             const f16x8 ah = *reinterpret_cast<const f16x8 *>(kh + col32 * AT_KSB + ks * 32 + 16 * half);
@@ -1406,19 +1509,21 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], sc, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], sc, 0, 0, 0);
         }
-        float mx = -INFINITY;
+        if (kb0 + AT_KB > T) {                       // only the clip's last block has keys past its end
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (kb0 + acc_row(r, half) >= T) sc[r] = -INFINITY;
-            mx = fmaxf(mx, sc[r]);
+            for (int r = 0; r < 16; ++r)
+                if (kb0 + acc_row(r, half) >= T) sc[r] = -INFINITY;
         }
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);            // finite: key kb0 < T is in every block
-        const float corr = __expf(m - m_new);
+        const float corr = __builtin_amdgcn_exp2f(m - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sc[r] = __expf(sc[r] - m_new);
+            sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
             psum += sc[r];
         }
         psum += __shfl_xor(psum, 32);
@@ -1453,6 +1558,11 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
                 o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ppl[ks], o[nt], 0, 0, 0);
                 o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pph[ks], o[nt], 0, 0, 0);
             }
+        if constexpr (PACKED) {
+            if (kb0 + AT_KB < k_end) store_block(buf ^ 1);
+            lds_barrier();
+            buf ^= 1;
+        }
     }
     if (q < T) {
         const float inv = l > 0.f ? 1.0f / l : 0.f;          // l == 0: an empty key range (its weight in the merge is 0)
@@ -1460,8 +1570,9 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float *__
         if (n_splits > 1) {
             op = part_o + (static_cast<long>(split) * total_rows + row0 + q) * 1024 + head * AT_D;
             if (half == 0) {
+                // the running maximum in natural-log units, as attention_merge_kernel weighs the ranges
                 float *ml = part_ml + ((static_cast<long>(split) * total_rows + row0 + q) * 8 + head) * 2;
-                ml[0] = m;
+                ml[0] = m * 0.6931471805599453f;
                 ml[1] = l;
             }
         }
@@ -1725,6 +1836,7 @@ struct ShakeScratch {
     size_t sync_bytes;
     float *x, *qkv, *att, *ff;               // ShakeTransformer
     float *part_o, *part_ml;                 // attention over several key ranges: partial outputs, (max, sum)
+    uint4 *kvp;                              // keys and values of the layer in flight as attention_pack_kernel's blocks
     int att_splits;
     size_t bytes;
 };
@@ -1778,6 +1890,9 @@ ShakeScratch carve_shake(void *ws, long n, long T, int kind, int num_cus = 0) {
         sc.qkv = take(static_cast<size_t>(n) * T4 * 3072);
         sc.att = take(static_cast<size_t>(n) * T4 * 1024);
         sc.ff = take(static_cast<size_t>(n) * T4 * 2048);
+        sc.kvp = nullptr;
+        if (T4 >= kAttentionPackTokens)
+            sc.kvp = reinterpret_cast<uint4 *>(take(static_cast<size_t>(n) * 8 * sedmi::ceil_div(T4, AT_KB) * (AT_BLOB / 4)));
         sc.att_splits = attention_splits(n, T4, num_cus);
         if (sc.att_splits > 1) {
             sc.part_o = take(static_cast<size_t>(sc.att_splits) * n * T4 * 1024);
@@ -1987,6 +2102,12 @@ int run_shake_gru(const sedmi_shake_rcnn *m, const float *seq, long n, int T4, c
     return SEDMI_OK;
 }
 
+// SEDMI_SHAKE_ATT_PACKED=0: every attention workgroup splits its keys and values itself (the comparison path)
+bool attention_packed_wanted() {
+    const char *e = std::getenv("SEDMI_SHAKE_ATT_PACKED");
+    return e == nullptr || e[0] != '0';
+}
+
 int run_encoder(const sedmi_shake_transformer *m, long n, int T4, const ShakeScratch &sc, hipStream_t s) {
     const long rows = n * T4;
     const unsigned ln_grid = static_cast<unsigned>(sedmi::ceil_div(rows, 4));
@@ -1999,9 +2120,23 @@ int run_encoder(const sedmi_shake_transformer *m, long n, int T4, const ShakeScr
             sedmi::ProfileScope prof("shake_tf_attention", s, 4.0 * n * 8 * static_cast<double>(T4) * T4 * AT_D,
                                      4.0 * rows * 4096.0);
             const int S = sc.att_splits > 1 ? sc.att_splits : 1;
-            hipLaunchKernelGGL(attention_split_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, 128) * S), 8, static_cast<unsigned>(n)),
-                               dim3(256), 0, s, sc.qkv, sc.att, T4, 1.0f / std::sqrt(static_cast<float>(AT_D)), S, sc.part_o,
-                               sc.part_ml, rows);
+            const dim3 agrid(static_cast<unsigned>(sedmi::ceil_div(T4, 128) * S), 8, static_cast<unsigned>(n));
+            const float qscale = 1.0f / std::sqrt(static_cast<float>(AT_D));
+            // keys and values once per layer in the kernel's own operand layout when enough query tiles walk each block
+            if (attention_packed_wanted() && sc.kvp != nullptr) {
+                hipLaunchKernelGGL(attention_pack_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(T4, AT_KB)), 8, static_cast<unsigned>(n)),
+                                   dim3(256), 0, s, sc.qkv, sc.kvp, T4);
+                SEDMI_CHECK_LAUNCH();
+                auto kern = attention_split_kernel<true>;
+                if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), 2 * AT_BLOB)) return rc_lds;
+                hipLaunchKernelGGL(kern, agrid, dim3(256), 2 * AT_BLOB, s, sc.qkv, sc.kvp, sc.att, T4, qscale, S, sc.part_o,
+                                   sc.part_ml, rows);
+            } else {
+                auto kern = attention_split_kernel<false>;
+                if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), AT_BLOB)) return rc_lds;
+                hipLaunchKernelGGL(kern, agrid, dim3(256), AT_BLOB, s, sc.qkv, sc.kvp, sc.att, T4, qscale, S, sc.part_o,
+                                   sc.part_ml, rows);
+            }
             SEDMI_CHECK_LAUNCH();
             if (S > 1) {
                 hipLaunchKernelGGL(attention_merge_kernel, dim3(static_cast<unsigned>(sedmi::ceil_div(rows * 256, 256))), dim3(256), 0,

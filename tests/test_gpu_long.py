@@ -67,6 +67,23 @@ def test_shake_transformer_240s_recording_6000_tokens_vs_oracle():
     np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_LOGITS)
 
 
+@pytest.mark.parametrize("n_clips, T", [(1, 4400), (3, 4100)])
+def test_attention_from_packed_key_blocks_agrees_bit_for_bit_with_the_per_workgroup_split(n_clips, T, monkeypatch):
+    # From 1024 tokens per clip on, the keys and values of a layer are split into f16 halves and laid out as the
+    # attention kernel's LDS planes once, by a pass of their own; below that (and with SEDMI_SHAKE_ATT_PACKED=0) every
+    # workgroup does it for itself.  Same operand bits, same products in the same order: identical logits.
+    # 4400 -> 1100 tokens = 34 key blocks + 12 keys; 4100 -> 1025 tokens = 32 blocks + 1 key
+    m, _ = _shake("transformer")
+    x = torch.from_numpy(synth.synth_shake_feats(50 + n_clips, n_clips, T)).cuda()
+    al = [0.4, 0.6, 0.2]
+    monkeypatch.setenv("SEDMI_SHAKE_ATT_PACKED", "1")
+    packed = m(x, al).cpu().numpy()
+    monkeypatch.setenv("SEDMI_SHAKE_ATT_PACKED", "0")
+    plain = m(x, al).cpu().numpy()
+    assert packed.shape == (n_clips, T // 4, 10) and np.isfinite(packed).all()
+    assert np.array_equal(packed, plain)
+
+
 @pytest.mark.parametrize("kind", ["rcnn", "transformer"])
 @pytest.mark.parametrize("T", [10, 37, 1001])
 def test_shake_frame_counts_are_floored_like_the_reference(kind, T):
