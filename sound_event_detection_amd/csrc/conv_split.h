@@ -21,6 +21,9 @@
 #ifndef SPLIT_GLU_BDIST
 #define SPLIT_GLU_BDIST 1     // same, for the GEMM of the GLU phases
 #endif
+#ifndef COLUMN_TILES
+#define COLUMN_TILES 1        // 0: the narrow blocks keep position-major m-tiles (the comparison build)
+#endif
 #ifdef SPLIT_TIMING
 // diagnostic build only: per-layer sums of s_memtime ticks spent in each section of conv_split_kernel
 // (wave 0 of every workgroup), read back through sedmi_debug_split_ticks
@@ -64,7 +67,15 @@ struct SplitGeom {
     static constexpr int NT = COUT / (32 * WAVES_N);
     static constexpr int M = 32 * MT * WAVES_M;          // positions per workgroup
     static constexpr int TH = M / W;                     // rows per workgroup
-    static constexpr int TW = W + 2;
+    // Column tiles (the narrow blocks, W <= 8): an m-tile is 32 consecutive ROWS of ONE column (m-tile g of the
+    // workgroup = column g % W of row group g / W) instead of 32 consecutive positions.  A tile of an edge column
+    // then skips the taps that would read the zero padding beside the image -- a third of the conv's MFMAs at W = 2,
+    // a sixth at W = 4 -- and the pooled pair of columns is the same register of two of the lane's accumulators.
+    // No tap reads a padding column any more, so the planes keep a single (never read) one: rows are W + 1
+    // positions apart, an odd number of 16-byte units, which keeps the row-strided fragment reads conflict-free.
+    // (MT % W == 0: which tiles are edge tiles is then the same in every wave, and known at compile time)
+    static constexpr bool COLT = W <= 8 && MT % W == 0 && TH % 32 == 0 && COLUMN_TILES;
+    static constexpr int TW = COLT ? W + 1 : W + 2;
     static constexpr int PSB = CCH * 2 + 16;             // bytes per position per plane (16 B pad)
     static constexpr int PLANE_A = (TH + 2) * TW * PSB;
     static constexpr int ZSB = COUT * 2 + 16;
@@ -185,6 +196,74 @@ __device__ __forceinline__ void split_gemm(f32x16 (&acc)[MT][NT], const char *(&
     }
 }
 
+// The same with m-tiles that sit some k-steps out: use(i, mt) says whether m-tile mt takes part in step i (every step
+// has at least one that does).  The fragment requested one step ahead is that of the step's FIRST participating
+// m-tile, and the request goes out in front of the MFMAs of the current step's LAST one.
+template <int MT, int NT, int NSTEPS, int D = SPLIT_BDIST, typename AOff, typename Use>
+__device__ __forceinline__ void split_gemm_some(f32x16 (&acc)[MT][NT], const char *(&ah)[MT], const char *(&al)[MT],
+                                                const uint4 *b, int N, AOff a_off, Use use) {
+    const int BS = N * 4, n2 = N * 2;
+    constexpr int NB = D + 1;
+    SplitB<NT> bb[NB];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < NSTEPS) split_load_b<NT>(bb[d], b + d * BS, n2);
+    auto first_of = [&](int i) {
+        int f = 0;
+#pragma unroll
+        for (int mt = MT - 1; mt >= 0; --mt)
+            if (use(i, mt)) f = mt;
+        return f;
+    };
+    auto last_of = [&](int i) {
+        int l = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (use(i, mt)) l = mt;
+        return l;
+    };
+    f16x8 ph = *reinterpret_cast<const f16x8 *>(ah[first_of(0)] + a_off(0));
+    f16x8 pl = *reinterpret_cast<const f16x8 *>(al[first_of(0)] + a_off(0));
+#pragma unroll
+    for (int i = 0; i < NSTEPS; ++i) {
+        if (i + D < NSTEPS) split_load_b<NT>(bb[(i + D) % NB], b + (i + D) * BS, n2);
+        __builtin_amdgcn_sched_barrier(0);
+        const SplitB<NT> &w = bb[i % NB];
+        const int first = first_of(i), last = last_of(i);
+        f16x8 vah[MT], val[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!use(i, mt)) continue;
+            if (mt == first) {
+                vah[mt] = ph;
+                val[mt] = pl;
+            } else {
+                vah[mt] = *reinterpret_cast<const f16x8 *>(ah[mt] + a_off(i));
+                val[mt] = *reinterpret_cast<const f16x8 *>(al[mt] + a_off(i));
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!use(i, mt)) continue;
+            if (mt == last) {
+                if (last != first) __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < NSTEPS) {
+                    ph = *reinterpret_cast<const f16x8 *>(ah[first_of(i + 1)] + a_off(i + 1));
+                    pl = *reinterpret_cast<const f16x8 *>(al[first_of(i + 1)] + a_off(i + 1));
+                }
+                if (last != first) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q == 0 ? val[mt] : vah[mt], q == 1 ? w.l[nt] : w.h[nt],
+                                                                         acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const float *__restrict__ x,       // [clip][H][W][CIN] f32
@@ -215,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const int h0 = static_cast<int>(tile % tiles_per_clip) * G::TH;
     const float *xc = x + clip * static_cast<long>(H) * W * CIN;
 
-    // zero the halo columns once (staging never writes them)
-    for (int i = tid; i < (G::TH + 2) * 2 * (G::PSB / 16); i += 256) {
+    // zero the halo columns once (staging never writes them; with column tiles nothing reads them)
+    for (int i = tid; !G::COLT && i < (G::TH + 2) * 2 * (G::PSB / 16); i += 256) {
         const int rr = i / (2 * (G::PSB / 16)), rem = i - rr * 2 * (G::PSB / 16);
         const int side = rem / (G::PSB / 16), o = (rem - side * (G::PSB / 16)) * 16;
         const int off = (rr * G::TW + side * (W + 1)) * G::PSB + o;
@@ -236,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int pos = 32 * MT * wm + 32 * mt + col32;
-        const int off = ((pos / W) * G::TW + pos % W) * G::PSB + 16 * half;
+        int off = ((pos / W) * G::TW + pos % W) * G::PSB + 16 * half;
+        // column tiles: row 32 * (g / W) + lane of column g % W, g = MT * wm + mt
+        if (G::COLT) off = ((32 * ((MT * wm + mt) / W) + col32) * G::TW + (MT * wm + mt) % W) * G::PSB + 16 * half;
         ah[mt] = plane_h + off;
         al[mt] = plane_l + off;
     }
@@ -290,11 +371,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         __syncthreads();
         SPLIT_TICK(2);
         if (c + 1 < G::NCHUNK) load_chunk(c + 1);
-        split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT,
-                                       [](int i) {
-                                           const int tap = i / G::KS, ks = i % G::KS;
-                                           return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
-                                       });
+        auto tap_off = [](int i) {
+            const int tap = i / G::KS, ks = i % G::KS;
+            return ((tap / 3) * G::TW + (tap % 3)) * G::PSB + ks * 32;
+        };
+        if constexpr (G::COLT) {
+            // the leftmost column has nothing to its left, the rightmost nothing to its right
+            split_gemm_some<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT, tap_off,
+                                               [](int i, int mt) {
+                                                   const int kx = (i / G::KS) % 3, col = mt % W;
+                                                   return !(kx == 0 && col == 0) && !(kx == 2 && col == W - 1);
+                                               });
+        } else {
+            split_gemm<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT, tap_off);
+        }
         SPLIT_TICK(3);
     }
 
@@ -323,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yc, 0, H * (W / 2) * COUT * 4, 0x00020000);
     // pooled position of (row h0 + pos / W, column pos % W) is h0 * W/2 + pos / 2 for even pos
     const int ybase = ((h0 * (W / 2) + 16 * MT * wm + 2 * half) * COUT + ncol) * 4;
+    static_assert(!G::COLT || (G::MG <= 2 && W % 2 == 0), "column tiles go through the GLU one or one column pair at a time");
     const uint4 *gbp = gp + ncol * 2 + half;
     constexpr int MG = G::MG, NPH = G::NPHASE;
     constexpr int NV = MG * NT * 16;          // z values per lane and phase
@@ -399,6 +490,28 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         SPLIT_TICK(7);
         // the next phase's planes are complete, and this phase's are free to be overwritten after it
         if (p + 1 < NPH) lds_barrier();
+        if constexpr (G::COLT) {
+            // m-tile mt is column mt % W and the lane's register r row acc_row(r, half) of the tile's 32 rows.  With one
+            // m-tile per phase an even column parks its gated values in its own (now free) accumulators and the odd
+            // column to its right adds its own and stores the pooled pair; with two, the phase is the pair.
+            const int last = p * MG + MG - 1;                                    // the m-tile that stores: an odd column
+            const int row0 = 32 * ((MT * wm + last) / W) + 4 * half;             // of register 0
+            const int yb = (((h0 + row0) * (W / 2) + (last % W) / 2) * COUT + ncol) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = fmaf(lin[MG - 1][nt][r], gsc[nt], gbias[nt]) * acc[last][nt][r];
+                    if (MG == 1 && p % 2 == 0) {
+                        acc[p][nt][r] = g;
+                    } else {
+                        const float left = MG == 1 ? acc[last - 1][nt][r]
+                                                   : fmaf(lin[0][nt][r], gsc[nt], gbias[nt]) * acc[last - 1][nt][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, left + g), yrsrc,
+                                                              yb + (acc_row(r, 0) * (W / 2) * COUT + 32 * nt) * 4, 0, 0);
+                    }
+                }
+        } else
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
