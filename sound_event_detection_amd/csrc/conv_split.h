@@ -61,12 +61,14 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned &hi, uns
 // CIN/COUT/W: layer geometry (input width W, output width W/2).
 // WAVES_M x WAVES_N = 4 waves; each wave owns MT x NT tiles of 32x32.
 // CCH: input channels staged per pass through LDS.
-template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
+// XT: workgroup tiles across the width (1: a tile spans the image; 2: a tile is one half of it, column tiles only).
+template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH, int XT = 1>
 struct SplitGeom {
+    static constexpr int WT = W / XT;                    // columns per workgroup tile
     static constexpr int WAVES_N = 4 / WAVES_M;
     static constexpr int NT = COUT / (32 * WAVES_N);
     static constexpr int M = 32 * MT * WAVES_M;          // positions per workgroup
-    static constexpr int TH = M / W;                     // rows per workgroup
+    static constexpr int TH = M / WT;                    // rows per workgroup
     // Column tiles (the narrow blocks, W <= 8): an m-tile is 32 consecutive ROWS of ONE column (m-tile g of the
     // workgroup = column g % W of row group g / W) instead of 32 consecutive positions.  A tile of an edge column
     // then skips the taps that would read the zero padding beside the image -- a third of the conv's MFMAs at W = 2,
@@ -74,8 +76,10 @@ struct SplitGeom {
     // No tap reads a padding column any more, so the planes keep a single (never read) one: rows are W + 1
     // positions apart, an odd number of 16-byte units, which keeps the row-strided fragment reads conflict-free.
     // (MT % W == 0: which tiles are edge tiles is then the same in every wave, and known at compile time)
-    static constexpr bool COLT = W <= 8 && MT % W == 0 && TH % 32 == 0 && COLUMN_TILES;
-    static constexpr int TW = COLT ? W + 1 : W + 2;
+    static constexpr bool COLT = WT <= 8 && MT % WT == 0 && TH % 32 == 0 && COLUMN_TILES;
+    // XT == 2: a half's outer neighbour column is real data (the other half's edge column) and both halves use one
+    // layout: WT + 2 positions, plus one of padding where that makes the row an even number of 16-byte units
+    static constexpr int TW = !COLT ? W + 2 : XT == 1 ? W + 1 : (((WT + 2) * (CCH * 2 + 16) / 16) % 2 ? WT + 2 : WT + 3);
     static constexpr int PSB = CCH * 2 + 16;             // bytes per position per plane (16 B pad)
     static constexpr int PLANE_A = (TH + 2) * TW * PSB;
     static constexpr int ZSB = COUT * 2 + 16;
@@ -90,8 +94,9 @@ struct SplitGeom {
     static constexpr int NCHUNK = CIN / CCH;
     static constexpr int KS = CCH / 16;                  // k-steps per tap per chunk
     static constexpr int KSTEPS = 9 * CIN / 16;
-    static_assert(WAVES_M * WAVES_N == 4 && NT >= 1 && M % W == 0 && CIN % CCH == 0 && CCH % 16 == 0 &&
-                      COUT % 32 == 0 && W % 2 == 0 && LDS_BYTES <= 160 * 1024, "unsupported split-conv geometry");
+    static_assert(WAVES_M * WAVES_N == 4 && NT >= 1 && M % WT == 0 && CIN % CCH == 0 && CCH % 16 == 0 &&
+                      COUT % 32 == 0 && W % 2 == 0 && LDS_BYTES <= 160 * 1024 && (XT == 1 || (XT == 2 && COLT && WT % 2 == 0)),
+                  "unsupported split-conv geometry");
 };
 
 // B (weight) fragments of one k-step for NT column tiles: hi and lo planes.
@@ -264,7 +269,9 @@ __device__ __forceinline__ void split_gemm_some(f32x16 (&acc)[MT][NT], const cha
     }
 }
 
-template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
+// XI: which of the XT tiles across the width this launch works on (a launch per half: which column is the image's
+// edge is then a compile-time fact).
+template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH, int XT = 1, int XI = 0>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const float *__restrict__ x,       // [clip][H][W][CIN] f32
     const uint4 *__restrict__ wp,      // packed split weights [KSTEPS][2][COUT][16] f16, order chunk/tap/k
@@ -273,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const float *__restrict__ g_s, const float *__restrict__ gb,      // lin / 2 = acc * g_s + gb (pool factor folded in)
     float *__restrict__ y,             // [clip][H][W/2][COUT] f32
     int H, int tiles_per_clip, unsigned n_tiles) {
-    using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH>;
-    constexpr int NT = G::NT;
+    using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH, XT>;
+    constexpr int NT = G::NT, WT = G::WT, X0 = XI * WT;      // X0: the tile's first image column
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *plane_h = smem, *plane_l = smem + G::LDS_BYTES / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     for (int mt = 0; mt < MT; ++mt) {
         const int pos = 32 * MT * wm + 32 * mt + col32;
         int off = ((pos / W) * G::TW + pos % W) * G::PSB + 16 * half;
-        // column tiles: row 32 * (g / W) + lane of column g % W, g = MT * wm + mt
-        if (G::COLT) off = ((32 * ((MT * wm + mt) / W) + col32) * G::TW + (MT * wm + mt) % W) * G::PSB + 16 * half;
+        // column tiles: row 32 * (g / WT) + lane of the tile's column g % WT, g = MT * wm + mt
+        if (G::COLT) off = ((32 * ((MT * wm + mt) / WT) + col32) * G::TW + (MT * wm + mt) % WT) * G::PSB + 16 * half;
         ah[mt] = plane_h + off;
         al[mt] = plane_l + off;
     }
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     // latency is exposed.  The clip's input sits behind a buffer descriptor that spans exactly the clip: rows above
     // it (negative offsets wrap to huge unsigned ones) and below it fall outside and read as zero -- the conv's
     // padding -- with no branch and no 64-bit address arithmetic.
-    constexpr int ROW_F4 = W * CCH / 4;
+    constexpr int ROW_F4 = WT * CCH / 4;
     static_assert(ROW_F4 <= 256 && 256 % ROW_F4 == 0, "a pass covers whole rows");
     constexpr int RPJ = 256 / ROW_F4, ROWS = G::TH + 2;
     constexpr int NLD = (ROWS + RPJ - 1) / RPJ;
@@ -340,17 +347,30 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xc), 0, H * W * CIN * 4, 0x00020000);
     const int rr0 = tid / ROW_F4, e0 = (tid % ROW_F4) * 4, w0 = e0 / CCH, ch0 = e0 % CCH;
-    const unsigned g_base = static_cast<unsigned>(((h0 - 1 + rr0) * W + w0) * CIN + ch0) * 4u;
+    const unsigned g_base = static_cast<unsigned>(((h0 - 1 + rr0) * W + X0 + w0) * CIN + ch0) * 4u;
     const int l_base = (rr0 * G::TW + 1 + w0) * G::PSB + ch0 * 2;
     // the last pass may reach past the staged rows: those threads read nothing (an offset out of range) and write nothing
     constexpr bool RAGGED = NLD * RPJ > ROWS;
     const bool in_last = !RAGGED || rr0 < ROWS - (NLD - 1) * RPJ;
+    // XT == 2: the column of the other half that borders this one, in passes of 256 / (CCH / 4) rows
+    constexpr int EQ = CCH / 4, ERP = 256 / EQ, NE = XT == 2 ? (ROWS + ERP - 1) / ERP : 0;
+    f32x4v ve[NE > 0 ? NE : 1];
+    const int er0 = tid / EQ, ech = (tid % EQ) * 4;
+    const unsigned ge_base =
+        static_cast<unsigned>(((h0 - 1 + er0) * W + (XI == 0 ? X0 + WT : X0 - 1)) * CIN + ech) * 4u;
+    const int le_base = (er0 * G::TW + (XI == 0 ? WT + 1 : 0)) * G::PSB + ech * 2;
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             unsigned off = g_base + static_cast<unsigned>(c * CCH * 4 + j * RPJ * W * CIN * 4);
             if (RAGGED && j == NLD - 1 && !in_last) off = 0xfffffff0u;
             v[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            unsigned off = ge_base + static_cast<unsigned>(c * CCH * 4 + j * ERP * W * CIN * 4);
+            if (er0 + j * ERP >= ROWS) off = 0xfffffff0u;
+            ve[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, static_cast<int>(off), 0, 0));
         }
     };
     load_chunk(0);
@@ -368,6 +388,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
                 *reinterpret_cast<uint2 *>(plane_l + l_base + j * RPJ * G::TW * G::PSB) = lo;
             }
         }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            uint2 hi, lo;
+            split2_f16(ve[j][0], ve[j][1], hi.x, lo.x);
+            split2_f16(ve[j][2], ve[j][3], hi.y, lo.y);
+            if (er0 + j * ERP < ROWS) {
+                *reinterpret_cast<uint2 *>(plane_h + le_base + j * ERP * G::TW * G::PSB) = hi;
+                *reinterpret_cast<uint2 *>(plane_l + le_base + j * ERP * G::TW * G::PSB) = lo;
+            }
+        }
         __syncthreads();
         SPLIT_TICK(2);
         if (c + 1 < G::NCHUNK) load_chunk(c + 1);
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
             // the leftmost column has nothing to its left, the rightmost nothing to its right
             split_gemm_some<MT, NT, 9 * G::KS>(acc, ah, al, bp + static_cast<long>(c) * (9 * G::KS) * (COUT * 4), COUT, tap_off,
                                                [](int i, int mt) {
-                                                   const int kx = (i / G::KS) % 3, col = mt % W;
+                                                   const int kx = (i / G::KS) % 3, col = X0 + mt % WT;     // image column
                                                    return !(kx == 0 && col == 0) && !(kx == 2 && col == W - 1);
                                                });
         } else {
@@ -491,12 +521,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(
         // the next phase's planes are complete, and this phase's are free to be overwritten after it
         if (p + 1 < NPH) lds_barrier();
         if constexpr (G::COLT) {
-            // m-tile mt is column mt % W and the lane's register r row acc_row(r, half) of the tile's 32 rows.  With one
+            // m-tile mt is the tile's column mt % WT and the lane's register r row acc_row(r, half) of the tile's 32 rows.  With one
             // m-tile per phase an even column parks its gated values in its own (now free) accumulators and the odd
             // column to its right adds its own and stores the pooled pair; with two, the phase is the pair.
             const int last = p * MG + MG - 1;                                    // the m-tile that stores: an odd column
-            const int row0 = 32 * ((MT * wm + last) / W) + 4 * half;             // of register 0
-            const int yb = (((h0 + row0) * (W / 2) + (last % W) / 2) * COUT + ncol) * 4;
+            const int row0 = 32 * ((MT * wm + last) / WT) + 4 * half;            // of register 0
+            const int yb = (((h0 + row0) * (W / 2) + (X0 + last % WT) / 2) * COUT + ncol) * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

@@ -59,6 +59,14 @@ namespace {
 // Blocks 4-6 (8, 4, 2 columns): 1 x 4 waves with 8 x 1 tiles, so that a wave's m-tiles are whole columns of the image
 // and which of them are edge columns is the same in every wave (conv_split.h, column tiles): per 4096 clips 6.50 ->
 // 5.88 ms, 3.13 -> 2.73 ms and 1.63 -> 1.21 ms against the 2 x 2 form with position-major tiles.
+// Block 3 (16 columns): the same in two launches, one per half of the image's width (a workgroup tile is 32 rows x 8
+// columns; the neighbouring half's edge column is staged as real data, the image's own edge column skips its outer
+// tap): 7.39 -> 7.22 ms per 4096 clips.
+#ifndef B3_WM
+#define B3_WM 1
+#define B3_MT 8
+#define B3_XT 2
+#endif
 #ifndef B4_WM
 #define B4_WM 1
 #define B4_MT 8
@@ -1159,24 +1167,27 @@ int launch_conv(const sedmi_crnn *m, int layer, const float *x, float *y, long n
     return SEDMI_OK;
 }
 
-template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH>
+template <int CIN, int COUT, int W, int WAVES_M, int MT, int CCH, int XT = 1, int XI = 0>
 int launch_conv_split(const sedmi_crnn *m, int layer, const float *x, float *y, long n_clips, int H, hipStream_t s) {
-    using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH>;
+    using G = SplitGeom<CIN, COUT, W, WAVES_M, MT, CCH, XT>;
     const int tiles = static_cast<int>(sedmi::ceil_div(H, G::TH));
     const size_t lds = G::LDS_BYTES;
-    auto kern = conv_split_kernel<CIN, COUT, W, WAVES_M, MT, CCH>;
+    auto kern = conv_split_kernel<CIN, COUT, W, WAVES_M, MT, CCH, XT, XI>;
     if (int rc_lds = sedmi::set_max_dynamic_lds(reinterpret_cast<const void *>(kern), lds)) return rc_lds;
     static const std::string name = "conv_split_kernel<" + std::to_string(CIN) + "," + std::to_string(COUT) + "," +
                                     std::to_string(W) + ">";
-    const double pos = static_cast<double>(n_clips) * H * W;
-    sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
-                             pos * 4.0 * (CIN + COUT / 2.0));
-    const unsigned n_tiles = static_cast<unsigned>(n_clips * tiles);
-    hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), lds, s, x,
-                       reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_ts[layer],
-                       reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles,
-                       n_tiles);
-    SEDMI_CHECK_LAUNCH();
+    {
+        const double pos = static_cast<double>(n_clips) * H * W / XT;       // a launch covers one of the XT tiles across the width
+        sedmi::ProfileScope prof(name.c_str(), s, pos * (2.0 * 9 * CIN * COUT + 2.0 * COUT * COUT),
+                                 pos * 4.0 * (CIN + COUT / 2.0));
+        const unsigned n_tiles = static_cast<unsigned>(n_clips * tiles);
+        hipLaunchKernelGGL(kern, dim3((n_tiles + 7) / 8 * 8), dim3(256), lds, s, x,
+                           reinterpret_cast<const uint4 *>(m->d_wps[layer]), m->d_ss[layer], m->d_ts[layer],
+                           reinterpret_cast<const uint4 *>(m->d_gps[layer]), m->d_gs[layer], m->d_gbh[layer], y, H, tiles,
+                           n_tiles);
+        SEDMI_CHECK_LAUNCH();
+    }
+    if constexpr (XI + 1 < XT) return launch_conv_split<CIN, COUT, W, WAVES_M, MT, CCH, XT, XI + 1>(m, layer, x, y, n_clips, H, s);
     return SEDMI_OK;
 }
 
@@ -1239,7 +1250,7 @@ int run_cnn(const sedmi_crnn *m, const float *feats, long n_clips, int T, float 
             for (long s0 = 0; s0 < nc; s0 += sub) {
                 const long ns = std::min<long>(sub, nc - s0);
                 if ((rc = launch_conv_split<32, 64, 32, 4, 2, 32>(m, 2, actB + s0 * Tp * 1024, actA + s0 * Tp * 1024, ns, Tp, s))) return rc;
-                if ((rc = launch_conv_split<64, 128, 16, CONV_WM, CONV_MT, 32>(m, 3, actA + s0 * Tp * 1024, actB + s0 * Tp * 1024, ns, Tp, s))) return rc;
+                if ((rc = launch_conv_split<64, 128, 16, B3_WM, B3_MT, 32, B3_XT>(m, 3, actA + s0 * Tp * 1024, actB + s0 * Tp * 1024, ns, Tp, s))) return rc;
                 if ((rc = launch_conv_split<128, 128, 8, B4_WM, B4_MT, 32>(m, 4, actB + s0 * Tp * 1024, actA + s0 * Tp * 512, ns, Tp, s))) return rc;
             }
             if ((rc = launch_conv_split<128, 128, 4, B56_WM, B56_MT, 32>(m, 5, actA, actB, nc, Tp, s))) return rc;

@@ -33,7 +33,10 @@ def bench_name(k):
     return None
 
 
-def mean_per_launch(path, counter):
+PROFILED_CLIPS = 1024 * 2          # the profiled command: one warm-up step and one timed step of 1024 clips
+
+
+def mean_per_launch(path, counter, counts=None):
     acc = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -42,17 +45,21 @@ def mean_per_launch(path, counter):
         if n:
             acc[n][0] += 1
             acc[n][1] += float(r["Counter_Value"])
+    if counts is not None:
+        counts.update({k: n for k, (n, _) in acc.items()})
     return {k: v / n for k, (n, v) in acc.items()}
 
 
 def main():
-    fetch = mean_per_launch(sys.argv[1], "FETCH_SIZE")
+    launches = {}
+    fetch = mean_per_launch(sys.argv[1], "FETCH_SIZE", launches)
     write = mean_per_launch(sys.argv[2], "WRITE_SIZE")
-    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py --clips 1024 (conv kernels: 512 clips "
-            "per launch, as in the default run; mel/GRU/head launches cover 1024 clips here, 4096 in the default run); "
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py --clips 1024 --steps 1 --warmup 1; "
+            "clips_per_launch = the 2048 clips of that run over the kernel's launches (a kernel that covers half the "
+            "image width per launch counts half the clips); "
             "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request; calibrated on a torch add in the same pass)")
     out = {k: dict(hbm_bytes_per_launch=1024.0 * (2.0 * fetch[k] + write.get(k, 0.0)), fetch_size_kib_raw=fetch[k],
-                   write_size_kib=write.get(k, 0.0), clips_per_launch=512 if k.startswith(("conv", "clip_scale")) else 1024, note=note)
+                   write_size_kib=write.get(k, 0.0), clips_per_launch=PROFILED_CLIPS / launches[k], note=note)
            for k in fetch}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
