@@ -69,16 +69,17 @@ struct SplitGeom {
     static constexpr int NT = COUT / (32 * WAVES_N);
     static constexpr int M = 32 * MT * WAVES_M;          // positions per workgroup
     static constexpr int TH = M / WT;                    // rows per workgroup
-    // Column tiles (the narrow blocks, W <= 8): an m-tile is 32 consecutive ROWS of ONE column (m-tile g of the
-    // workgroup = column g % W of row group g / W) instead of 32 consecutive positions.  A tile of an edge column
-    // then skips the taps that would read the zero padding beside the image -- a third of the conv's MFMAs at W = 2,
-    // a sixth at W = 4 -- and the pooled pair of columns is the same register of two of the lane's accumulators.
-    // No tap reads a padding column any more, so the planes keep a single (never read) one: rows are W + 1
-    // positions apart, an odd number of 16-byte units, which keeps the row-strided fragment reads conflict-free.
-    // (MT % W == 0: which tiles are edge tiles is then the same in every wave, and known at compile time)
+    // Column tiles (workgroup tiles of up to 8 columns): an m-tile is 32 consecutive ROWS of ONE column (m-tile g of
+    // the workgroup = column g % WT of row group g / WT) instead of 32 consecutive positions.  The tile of an image
+    // edge column then skips the taps that would read the zero padding beside the image -- a third of the conv's
+    // MFMAs at W = 2, a sixth at W = 4, a twelfth at W = 8 -- and the pooled pair of columns is the same register of
+    // two of the lane's accumulators.  No tap reads a padding column any more, so the planes keep a single (never
+    // read) one: rows are W + 1 positions apart, an odd number of 16-byte units, which keeps the row-strided
+    // fragment reads conflict-free.
+    // (MT % WT == 0: which tiles are edge tiles is then the same in every wave, and known at compile time)
     static constexpr bool COLT = WT <= 8 && MT % WT == 0 && TH % 32 == 0 && COLUMN_TILES;
-    // XT == 2: a half's outer neighbour column is real data (the other half's edge column) and both halves use one
-    // layout: WT + 2 positions, plus one of padding where that makes the row an even number of 16-byte units
+    // XT == 2: a half's inner neighbour column is real data (the other half's edge column) and both halves use one
+    // layout: WT + 2 positions, plus one of padding where the row would otherwise be an even number of 16-byte units
     static constexpr int TW = !COLT ? W + 2 : XT == 1 ? W + 1 : (((WT + 2) * (CCH * 2 + 16) / 16) % 2 ? WT + 2 : WT + 3);
     static constexpr int PSB = CCH * 2 + 16;             // bytes per position per plane (16 B pad)
     static constexpr int PLANE_A = (TH + 2) * TW * PSB;
