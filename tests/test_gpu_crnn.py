@@ -158,16 +158,17 @@ def test_batch_independence_and_determinism(precision):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_batches_larger_than_one_pass_through_the_conv_stack(precision):
-    """The conv stack takes 512 clips per pass and the GRU / head kernels tile the whole batch: 1061 clips (two
-    full passes and a ragged third) of six distinct feature maps must give, at every batch position, the bits the
-    same feature map gives in a batch of its own -- first, last and straddling positions of every pass included."""
+    """The conv stack takes 1024 clips per pass (blocks 2-4 in inner passes of 512) and the GRU / head kernels tile
+    the whole batch: 2085 clips (two full passes and a ragged third of 37) of six distinct feature maps must give, at
+    every batch position, the bits the same feature map gives in a batch of its own -- first, last and straddling
+    positions of every outer and inner pass included."""
     m, _ = _model(2, 10, precision)
     g = torch.Generator(device="cuda").manual_seed(11)
     base = torch.rand(6, 501, 128, device="cuda", generator=g) * 3
     want = m(base)
-    idx = torch.arange(1061, device="cuda") % 6
+    idx = torch.arange(2085, device="cuda") % 6
     got = m(base[idx].contiguous())
-    assert got.shape == (1061, 250, 10)
+    assert got.shape == (2085, 250, 10)
     assert torch.equal(got, want[idx])
 
 
