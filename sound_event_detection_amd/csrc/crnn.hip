@@ -65,7 +65,7 @@ namespace {
 #ifndef B3_WM
 #define B3_WM 1
 #define B3_MT 8
-#define B3_XT 2
+#define B3_XT (COLUMN_TILES ? 2 : 1)      // half-width workgroup tiles exist as column tiles only
 #endif
 #ifndef B4_WM
 #define B4_WM 1
